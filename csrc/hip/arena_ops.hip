@@ -1,0 +1,339 @@
+// Flat-arena kernels for gfx950: everything the federation does to a model
+// between local-training steps is an elementwise pass or a reduction over one
+// contiguous fp32 buffer (the parameter arena), so each operation is a single
+// launch regardless of how many tensors the model has.
+//
+//   nf_weighted_sum       out = sum_k w_k * src_k           (FedAvg / share sum)
+//   nf_sqnorm_finite      sum of squares + count of non-finite values
+//   nf_clip_noise         out = in * min(1, C/(||in||+eps)) + N(0, std^2)
+//   nf_sgd_step           p -= lr * (g + wd * p); optional grad zeroing and
+//                         bf16 shadow copy of p
+//   nf_philox_fill        out (+)= scale * {uniform, normal, laplace, sym-uniform}
+//   nf_scale_accumulate   out = a * out + b * in
+//
+// All are HBM-bandwidth bound: 16-byte vector accesses, grid capped at 2048
+// blocks of 256 threads with a grid-stride loop, wave64 shuffle reductions.
+// Scalars that depend on device results (weights, the squared norm) are read
+// from device memory, so sequences of these kernels can be captured in a
+// hipGraph without host round trips.  Nothing here uses hipMemsetAsync:
+// reduction partials are fully overwritten by the first stage.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#include "../common/philox.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;
+constexpr int kMaxSources = 64;
+
+inline int grid_for(long n_vec) {
+    long blocks = (n_vec + kThreads - 1) / kThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    return static_cast<int>(blocks);
+}
+
+struct SourceTable {
+    const float* src[kMaxSources];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block-wide sum of two values; result valid in thread 0.
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+    __shared__ float sa[kThreads / 64];
+    __shared__ float sb[kThreads / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) { ta += sa[w]; tb += sb[w]; }
+        a = ta; b = tb;
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+weighted_sum_kernel(float* __restrict__ out, SourceTable table,
+                    const float* __restrict__ weights, int k, long n,
+                    int accumulate) {
+    __shared__ float w[kMaxSources];
+    if (threadIdx.x < k) w[threadIdx.x] = weights[threadIdx.x];
+    __syncthreads();
+
+    const long n4 = n >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4;
+         i += stride) {
+        float4 acc = accumulate ? reinterpret_cast<const float4*>(out)[i]
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < k; ++s) {
+            const float4 v = reinterpret_cast<const float4*>(table.src[s])[i];
+            const float ws = w[s];
+            acc.x = fmaf(ws, v.x, acc.x);
+            acc.y = fmaf(ws, v.y, acc.y);
+            acc.z = fmaf(ws, v.z, acc.z);
+            acc.w = fmaf(ws, v.w, acc.w);
+        }
+        reinterpret_cast<float4*>(out)[i] = acc;
+    }
+    // tail (n not a multiple of 4)
+    const long tail0 = n4 << 2;
+    const long t = tail0 + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float acc = accumulate ? out[t] : 0.f;
+        for (int s = 0; s < k; ++s) acc = fmaf(w[s], table.src[s][t], acc);
+        out[t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+sqnorm_finite_stage1(const float* __restrict__ x, long n,
+                     float* __restrict__ partial /* [2 * gridDim.x] */) {
+    float sq = 0.f, bad = 0.f;
+    const long n4 = n >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4;
+         i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = isfinite(e[j]);
+            sq += ok ? e[j] * e[j] : 0.f;
+            bad += ok ? 0.f : 1.f;
+        }
+    }
+    const long t = (n4 << 2) + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float e = x[t];
+        const bool ok = isfinite(e);
+        sq += ok ? e * e : 0.f;
+        bad += ok ? 0.f : 1.f;
+    }
+    block_sum2(sq, bad);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sq;
+        partial[2 * blockIdx.x + 1] = bad;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+sqnorm_finite_stage2(const float* __restrict__ partial, int blocks,
+                     float* __restrict__ out /* [2] */) {
+    float sq = 0.f, bad = 0.f;
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) {
+        sq += partial[2 * i];
+        bad += partial[2 * i + 1];
+    }
+    block_sum2(sq, bad);
+    if (threadIdx.x == 0) { out[0] = sq; out[1] = bad; }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+clip_noise_kernel(const float* __restrict__ in, float* __restrict__ out, long n,
+                  const float* __restrict__ sqnorm, float max_norm, float noise_std,
+                  unsigned long long seed, unsigned long long offset) {
+    const float norm = sqrtf(sqnorm[0]);
+    const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    const long n4 = (n + 3) >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long b = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; b < n4;
+         b += stride) {
+        float z[4];
+        nf::philox_samples(seed, offset, static_cast<unsigned long long>(b), 1, z);
+        const long base = b << 2;
+        if (base + 3 < n) {
+            const float4 v = reinterpret_cast<const float4*>(in)[b];
+            float4 r;
+            r.x = fmaf(v.x, coef, noise_std * z[0]);
+            r.y = fmaf(v.y, coef, noise_std * z[1]);
+            r.z = fmaf(v.z, coef, noise_std * z[2]);
+            r.w = fmaf(v.w, coef, noise_std * z[3]);
+            reinterpret_cast<float4*>(out)[b] = r;
+        } else {
+            for (int j = 0; j < 4 && base + j < n; ++j)
+                out[base + j] = fmaf(in[base + j], coef, noise_std * z[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, long n, float lr,
+                float weight_decay, int zero_grad,
+                __hip_bfloat16* __restrict__ shadow) {
+    const long n4 = n >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4;
+         i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        pv.x -= lr * fmaf(weight_decay, pv.x, gv.x);
+        pv.y -= lr * fmaf(weight_decay, pv.y, gv.y);
+        pv.z -= lr * fmaf(weight_decay, pv.z, gv.z);
+        pv.w -= lr * fmaf(weight_decay, pv.w, gv.w);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        if (zero_grad)
+            reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (shadow) {
+            __hip_bfloat16 h[4] = {__float2bfloat16(pv.x), __float2bfloat16(pv.y),
+                                   __float2bfloat16(pv.z), __float2bfloat16(pv.w)};
+            reinterpret_cast<uint2*>(shadow)[i] = *reinterpret_cast<uint2*>(h);
+        }
+    }
+    const long t = (n4 << 2) + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float pv = p[t];
+        pv -= lr * fmaf(weight_decay, pv, g[t]);
+        p[t] = pv;
+        if (zero_grad) g[t] = 0.f;
+        if (shadow) shadow[t] = __float2bfloat16(pv);
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+philox_fill_kernel(float* __restrict__ out, long n, unsigned long long seed,
+                   unsigned long long offset, long first, int mode, float scale,
+                   int accumulate) {
+    // element e = first + i; block b = e >> 2. Iterate over the blocks that
+    // overlap [first, first + n).
+    const long b0 = first >> 2;
+    const long b1 = (first + n + 3) >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long b = b0 + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; b < b1;
+         b += stride) {
+        float s[4];
+        nf::philox_samples(seed, offset, static_cast<unsigned long long>(b), mode, s);
+        const long i0 = (b << 2) - first;
+        if (i0 >= 0 && i0 + 3 < n && ((reinterpret_cast<uintptr_t>(out + i0) & 15) == 0)) {
+            float4 v = accumulate ? *reinterpret_cast<float4*>(out + i0)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = fmaf(scale, s[0], v.x);
+            v.y = fmaf(scale, s[1], v.y);
+            v.z = fmaf(scale, s[2], v.z);
+            v.w = fmaf(scale, s[3], v.w);
+            *reinterpret_cast<float4*>(out + i0) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long i = i0 + j;
+                if (i >= 0 && i < n) {
+                    const float base = accumulate ? out[i] : 0.f;
+                    out[i] = fmaf(scale, s[j], base);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+scale_accumulate_kernel(float* __restrict__ out, const float* __restrict__ in, long n,
+                        float a, float b) {
+    const long n4 = n >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4;
+         i += stride) {
+        float4 o = reinterpret_cast<float4*>(out)[i];
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        o.x = fmaf(b, v.x, a * o.x);
+        o.y = fmaf(b, v.y, a * o.y);
+        o.z = fmaf(b, v.z, a * o.z);
+        o.w = fmaf(b, v.w, a * o.w);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+    const long t = (n4 << 2) + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = fmaf(b, in[t], a * out[t]);
+}
+
+}  // namespace
+
+#define NF_CHECK_LAUNCH() (static_cast<int>(hipGetLastError()))
+
+extern "C" {
+
+int nf_max_sources() { return kMaxSources; }
+int nf_reduce_workspace_floats() { return 2 * kMaxBlocks + 2; }
+
+// srcs: host array of k device pointers; weights: device pointer to k floats.
+int nf_weighted_sum(float* out, const float* const* srcs, const float* weights,
+                    int k, long n, int accumulate, hipStream_t stream) {
+    if (k < 1 || k > kMaxSources || n < 0) return -1;
+    if (n == 0) return 0;
+    SourceTable table;
+    for (int i = 0; i < kMaxSources; ++i) table.src[i] = i < k ? srcs[i] : nullptr;
+    const int grid = grid_for((n + 3) >> 2);
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(grid), dim3(kThreads), 0, stream,
+                       out, table, weights, k, n, accumulate);
+    return NF_CHECK_LAUNCH();
+}
+
+// workspace: device buffer of nf_reduce_workspace_floats() floats.
+// result: device buffer of 2 floats (sum of squares over finite values,
+// number of non-finite values).
+int nf_sqnorm_finite(const float* x, long n, float* workspace, float* result,
+                     hipStream_t stream) {
+    if (n < 0) return -1;
+    const int grid = grid_for((n + 3) >> 2);
+    hipLaunchKernelGGL(sqnorm_finite_stage1, dim3(grid), dim3(kThreads), 0, stream,
+                       x, n, workspace);
+    hipLaunchKernelGGL(sqnorm_finite_stage2, dim3(1), dim3(kThreads), 0, stream,
+                       workspace, grid, result);
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_clip_noise(const float* in, float* out, long n, const float* sqnorm,
+                  float max_norm, float noise_std, unsigned long long seed,
+                  unsigned long long offset, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    const int grid = grid_for((n + 3) >> 2);
+    hipLaunchKernelGGL(clip_noise_kernel, dim3(grid), dim3(kThreads), 0, stream, in,
+                       out, n, sqnorm, max_norm, noise_std, seed, offset);
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_sgd_step(float* p, float* g, long n, float lr, float weight_decay,
+                int zero_grad, void* bf16_shadow, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    const int grid = grid_for((n + 3) >> 2);
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(grid), dim3(kThreads), 0, stream, p, g,
+                       n, lr, weight_decay, zero_grad,
+                       static_cast<__hip_bfloat16*>(bf16_shadow));
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_philox_fill(float* out, long n, unsigned long long seed,
+                   unsigned long long offset, long first, int mode, float scale,
+                   int accumulate, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    const int grid = grid_for((n + 3) >> 2);
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(grid), dim3(kThreads), 0, stream, out,
+                       n, seed, offset, first, mode, scale, accumulate);
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_scale_accumulate(float* out, const float* in, long n, float a, float b,
+                        hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    const int grid = grid_for((n + 3) >> 2);
+    hipLaunchKernelGGL(scale_accumulate_kernel, dim3(grid), dim3(kThreads), 0, stream,
+                       out, in, n, a, b);
+    return NF_CHECK_LAUNCH();
+}
+
+}  // extern "C"

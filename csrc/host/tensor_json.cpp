@@ -1,0 +1,202 @@
+// Tensor <-> JSON nested-list codec for the HTTP wire format.
+//
+// The wire schema carries every tensor as nested JSON lists of numbers.  Going
+// through Python float objects (tensor.tolist() -> json.dumps, json.loads ->
+// torch.tensor) costs seconds for a 1.2M-parameter model.  These two functions
+// convert directly between a contiguous fp32 buffer and JSON text:
+//
+//  * encode: shortest decimal that round-trips the fp32 value (std::to_chars),
+//    so the text is about half the size of repr(float64(x)) and parses back to
+//    the identical fp32;
+//  * decode: parses a (possibly ragged-free) nested list of numbers, returning
+//    the shape and the values as fp32; "NaN", "Infinity" and "-Infinity" (what
+//    Python's json emits) are accepted.
+//
+// C ABI, loaded with ctypes (nanofed_amd/communication/codec.py).
+
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace {
+
+struct Writer {
+    char* out;
+    long cap;
+    long pos = 0;
+    bool overflow = false;
+    void put(char c) {
+        if (pos < cap) out[pos] = c; else overflow = true;
+        ++pos;
+    }
+    void put(const char* s) { while (*s) put(*s++); }
+    void number(float v) {
+        if (std::isnan(v)) { put("NaN"); return; }
+        if (std::isinf(v)) { put(v > 0 ? "Infinity" : "-Infinity"); return; }
+        char buf[48];
+        auto r = std::to_chars(buf, buf + sizeof(buf), v);
+        bool is_int = true;
+        for (char* p = buf; p != r.ptr; ++p)
+            if (*p == '.' || *p == 'e' || *p == 'n' || *p == 'i') is_int = false;
+        for (char* p = buf; p != r.ptr; ++p) put(*p);
+        if (is_int) put(".0");  // keep it a JSON float, as tolist() would
+    }
+};
+
+void encode_rec(Writer& w, const float*& data, const long* shape, int ndim) {
+    if (ndim == 0) { w.number(*data++); return; }
+    w.put('[');
+    for (long i = 0; i < shape[0]; ++i) {
+        if (i) { w.put(','); w.put(' '); }
+        encode_rec(w, data, shape + 1, ndim - 1);
+    }
+    w.put(']');
+}
+
+struct Reader {
+    const char* p;
+    const char* end;
+    float* out;
+    long cap;
+    long count = 0;
+    long shape[8];
+    bool seen[8];
+    int max_depth = 0;
+    bool fail = false;
+
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+
+    bool literal(const char* s, float v) {
+        const size_t n = std::strlen(s);
+        if (static_cast<size_t>(end - p) >= n && std::memcmp(p, s, n) == 0) {
+            p += n;
+            emit(v);
+            return true;
+        }
+        return false;
+    }
+    void emit(float v) {
+        if (count < cap) out[count] = v;
+        ++count;
+    }
+    void value(int depth) {
+        ws();
+        if (p >= end) { fail = true; return; }
+        if (*p == '[') {
+            if (depth >= 8) { fail = true; return; }
+            ++p;
+            long n = 0;
+            ws();
+            if (p < end && *p == ']') { ++p; }
+            else {
+                for (;;) {
+                    value(depth + 1);
+                    if (fail) return;
+                    ++n;
+                    ws();
+                    if (p < end && *p == ',') { ++p; continue; }
+                    if (p < end && *p == ']') { ++p; break; }
+                    fail = true; return;
+                }
+            }
+            if (!seen[depth]) { seen[depth] = true; shape[depth] = n; }
+            else if (shape[depth] != n) { fail = true; return; }
+            if (depth + 1 > max_depth) max_depth = depth + 1;
+            return;
+        }
+        if (literal("NaN", NAN) || literal("Infinity", INFINITY) ||
+            literal("-Infinity", -INFINITY))
+            return;
+        if (literal("true", 1.0f) || literal("false", 0.0f)) return;
+        double d = 0;
+        auto r = std::from_chars(p, end, d);
+        if (r.ec != std::errc()) { fail = true; return; }
+        p = r.ptr;
+        emit(static_cast<float>(d));
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Upper bound on the encoded size: 16 chars per number + separators/brackets.
+long nf_json_encode_bound(long numel, int ndim) {
+    return numel * 20 + 4 * ndim + 16;
+}
+
+// Returns bytes written, or -needed when cap is too small.
+long nf_json_encode_f32(const float* data, const long* shape, int ndim,
+                        char* out, long cap) {
+    Writer w{out, cap};
+    const float* cursor = data;
+    encode_rec(w, cursor, shape, ndim);
+    return w.overflow ? -w.pos : w.pos;
+}
+
+// Parses one JSON value (number or nested list). On success returns the number
+// of values (written to out up to cap; when the count exceeds cap the caller
+// retries with a larger buffer), fills shape[0..ndim). Returns -1 on malformed
+// or ragged input.
+//
+// consumed_out == nullptr: the value must span the whole text (trailing white
+// space allowed). Otherwise the number of bytes the value occupied is stored
+// there and whatever follows is left to the caller.
+long nf_json_decode_f32(const char* text, long len, float* out, long cap,
+                        long* shape_out, int* ndim_out, long* consumed_out) {
+    Reader r{text, text + len, out, cap};
+    for (int i = 0; i < 8; ++i) { r.seen[i] = false; r.shape[i] = 0; }
+    r.value(0);
+    if (r.fail) return -1;
+    if (consumed_out) {
+        *consumed_out = r.p - text;
+    } else {
+        r.ws();
+        if (r.p != r.end) return -1;
+    }
+    *ndim_out = r.max_depth;
+    for (int i = 0; i < r.max_depth; ++i) shape_out[i] = r.shape[i];
+    return r.count;
+}
+
+// Returns the offset one past the JSON value that starts at `pos` (after
+// optional white space), or -1 if the text ends inside it. Strings, escapes and
+// nesting are honoured; numbers/literals end at the first of ",]} \t\r\n".
+long nf_json_skip_value(const char* text, long len, long pos) {
+    const char* p = text + pos;
+    const char* end = text + len;
+    while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    if (p >= end) return -1;
+    if (*p == '"') {
+        for (++p; p < end; ++p) {
+            if (*p == '\\') { ++p; continue; }
+            if (*p == '"') return (p + 1) - text;
+        }
+        return -1;
+    }
+    if (*p == '[' || *p == '{') {
+        long depth = 0;
+        bool in_str = false;
+        for (; p < end; ++p) {
+            const char c = *p;
+            if (in_str) {
+                if (c == '\\') { ++p; continue; }
+                if (c == '"') in_str = false;
+                continue;
+            }
+            if (c == '"') in_str = true;
+            else if (c == '[' || c == '{') ++depth;
+            else if (c == ']' || c == '}') {
+                if (--depth == 0) return (p + 1) - text;
+            }
+        }
+        return -1;
+    }
+    while (p < end && *p != ',' && *p != ']' && *p != '}' && *p != ' ' &&
+           *p != '\n' && *p != '\t' && *p != '\r')
+        ++p;
+    return p - text;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""Model-state codec for the HTTP wire format.
+
+The wire schema (reference: nanofed/communication/http/types.py:14-50) carries
+``model_state`` as ``{name: nested JSON lists}``.  The reference produces and
+consumes it through Python float objects; for the 1.2M-parameter CNN that is
+~25 MB of text and 1-2 s per transfer.  Here the tensors are converted
+directly between fp32 buffers and JSON text by the native codec
+(csrc/host/tensor_json.cpp), and the small envelope (ids, metrics, timestamps)
+is still handled by the standard ``json`` module.  The text produced is plain
+JSON that any reference client or server can parse.
+
+``encode_state_json`` / ``decode_state_json`` work on the ``model_state``
+object alone; ``dumps_envelope`` / ``loads_envelope`` splice it in and out of
+a full request or response body.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import json
+from ctypes import POINTER, c_char_p, c_int, c_long, c_void_p
+from functools import lru_cache
+from typing import Any
+
+import numpy as np
+import torch
+
+_STATE_KEY = '"model_state"'
+_PLACEHOLDER = "__nanofed_model_state__"
+
+
+@lru_cache(maxsize=1)
+def _lib() -> ctypes.CDLL:
+    from nanofed_amd import native_build
+
+    if not native_build.HOST_LIB.exists():
+        native_build.build_host()
+    lib = ctypes.CDLL(str(native_build.HOST_LIB))
+    lib.nf_json_encode_bound.restype = c_long
+    lib.nf_json_encode_bound.argtypes = [c_long, c_int]
+    lib.nf_json_encode_f32.restype = c_long
+    lib.nf_json_encode_f32.argtypes = [
+        c_void_p, POINTER(c_long), c_int, c_void_p, c_long]
+    lib.nf_json_decode_f32.restype = c_long
+    lib.nf_json_decode_f32.argtypes = [
+        c_char_p, c_long, c_void_p, c_long, POINTER(c_long), POINTER(c_int),
+        POINTER(c_long)]
+    lib.nf_json_skip_value.restype = c_long
+    lib.nf_json_skip_value.argtypes = [c_char_p, c_long, c_long]
+    return lib
+
+
+def native_available() -> bool:
+    try:
+        _lib()
+        return True
+    except Exception:
+        return False
+
+
+def encode_tensor_json(tensor: torch.Tensor) -> bytes:
+    """Nested-list JSON text of ``tensor`` (as fp32; integers keep a ``.0``)."""
+    arr = np.ascontiguousarray(
+        tensor.detach().to("cpu", torch.float32).numpy()
+    )
+    lib = _lib()
+    shape = (c_long * max(arr.ndim, 1))(*arr.shape)
+    cap = int(lib.nf_json_encode_bound(arr.size, arr.ndim))
+    buf = ctypes.create_string_buffer(cap)
+    n = lib.nf_json_encode_f32(
+        arr.ctypes.data_as(c_void_p), shape, arr.ndim, buf, cap
+    )
+    if n < 0:
+        buf = ctypes.create_string_buffer(-n + 16)
+        n = lib.nf_json_encode_f32(
+            arr.ctypes.data_as(c_void_p), shape, arr.ndim, buf, -n + 16
+        )
+    return buf.raw[:n]
+
+
+def _decode_prefix(text: bytes, pos: int) -> tuple[torch.Tensor, int]:
+    """Decode the JSON value starting at ``text[pos]``; returns (tensor, end)."""
+    lib = _lib()
+    end = int(lib.nf_json_skip_value(text, len(text), pos))
+    if end < 0:
+        raise ValueError("Truncated JSON value in model_state")
+    piece = text[pos:end]
+    # a number takes at least 2 bytes ("0,") so len/2 bounds the value count
+    cap = len(piece) // 2 + 2
+    out = np.empty(cap, dtype=np.float32)
+    shape = (c_long * 8)()
+    ndim = c_int(0)
+    n = lib.nf_json_decode_f32(
+        piece, len(piece), out.ctypes.data_as(c_void_p), cap, shape,
+        ctypes.byref(ndim), None,
+    )
+    if n < 0 or n > cap:
+        raise ValueError("Malformed tensor in model_state")
+    dims = tuple(int(shape[i]) for i in range(ndim.value))
+    tensor = torch.from_numpy(out[:n].copy()).reshape(dims)
+    return tensor, end
+
+
+def encode_state_json(state: dict[str, Any]) -> bytes:
+    """``{"name": [[...]], ...}`` for a dict of tensors (or nested lists)."""
+    parts = []
+    for name, value in state.items():
+        if isinstance(value, torch.Tensor):
+            body = encode_tensor_json(value)
+        else:
+            body = json.dumps(value).encode()
+        parts.append(json.dumps(str(name)).encode() + b": " + body)
+    return b"{" + b", ".join(parts) + b"}"
+
+
+def decode_state_json(text: bytes) -> dict[str, torch.Tensor]:
+    """Inverse of :func:`encode_state_json` for list-valued states."""
+    pos = text.find(b"{")
+    if pos < 0:
+        raise ValueError("model_state is not a JSON object")
+    pos += 1
+    lib = _lib()
+    state: dict[str, torch.Tensor] = {}
+    n = len(text)
+    while True:
+        while pos < n and text[pos : pos + 1] in b" \n\t\r,":
+            pos += 1
+        if pos >= n:
+            raise ValueError("Unterminated model_state object")
+        if text[pos : pos + 1] == b"}":
+            return state
+        key_end = int(lib.nf_json_skip_value(text, n, pos))
+        if key_end < 0 or text[pos : pos + 1] != b'"':
+            raise ValueError("Malformed key in model_state")
+        key = json.loads(text[pos:key_end])
+        pos = text.find(b":", key_end) + 1
+        if pos <= 0:
+            raise ValueError("Missing ':' in model_state")
+        tensor, pos = _decode_prefix(text, pos)
+        state[key] = tensor
+
+
+def dumps_envelope(payload: dict[str, Any]) -> bytes:
+    """JSON body for ``payload``; a tensor-valued ``model_state`` entry is
+    encoded natively, everything else with ``json``."""
+    state = payload.get("model_state")
+    if not isinstance(state, dict) or not native_available():
+        return json.dumps(_plain(payload)).encode()
+    shell = dict(payload)
+    shell["model_state"] = _PLACEHOLDER
+    text = json.dumps(_plain(shell)).encode()
+    return text.replace(
+        json.dumps(_PLACEHOLDER).encode(), encode_state_json(state), 1
+    )
+
+
+def loads_envelope(body: bytes) -> dict[str, Any]:
+    """Parse a request/response body.  ``model_state`` comes back as a dict of
+    fp32 tensors (or ``None``); the other fields as plain JSON values."""
+    if not native_available():
+        data = json.loads(body)
+        if isinstance(data.get("model_state"), dict):
+            data["model_state"] = {
+                k: torch.tensor(v, dtype=torch.float32)
+                for k, v in data["model_state"].items()
+            }
+        return data
+    at = body.find(_STATE_KEY.encode())
+    if at < 0:
+        return json.loads(body)
+    colon = body.find(b":", at + len(_STATE_KEY))
+    lib = _lib()
+    end = int(lib.nf_json_skip_value(body, len(body), colon + 1))
+    if end < 0:
+        raise ValueError("Truncated model_state")
+    value = body[colon + 1 : end]
+    envelope = json.loads(body[: colon + 1] + b" null" + body[end:])
+    stripped = value.strip()
+    if stripped.startswith(b"{"):
+        envelope["model_state"] = decode_state_json(value)
+    else:
+        envelope["model_state"] = json.loads(value)
+    return envelope
+
+
+def _plain(value: Any) -> Any:
+    if isinstance(value, torch.Tensor):
+        return value.detach().cpu().tolist()
+    if isinstance(value, np.ndarray):
+        return value.tolist()
+    if isinstance(value, dict):
+        return {k: _plain(v) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_plain(v) for v in value]
+    if hasattr(value, "__dataclass_fields__"):
+        return {f: _plain(getattr(value, f)) for f in value.__dataclass_fields__}
+    return value

@@ -1,0 +1,252 @@
+"""aiohttp federation server (reference: nanofed/communication/http/server.py:29-340).
+
+Routes: ``GET /model`` (current global model + round number, or the
+``terminated`` payload once training is over; 500 without a coordinator),
+``POST /update`` (400 on missing keys or a stale round number; last writer
+wins per client), ``GET /status``, ``GET /test``.
+
+Bodies are standard JSON.  Tensors are encoded/decoded by the native codec
+(``nanofed_amd.communication.codec``), so a stored update's ``model_state``
+holds fp32 tensors rather than nested lists; consumers accept either.
+
+The round number has one source of truth: the coordinator advances
+``_current_round`` through :meth:`advance_round` when a round completes, so a
+late update for a finished round is rejected instead of leaking into the next
+round.
+"""
+
+from __future__ import annotations
+
+import asyncio
+from dataclasses import dataclass
+from typing import TYPE_CHECKING, Any
+
+import numpy as np
+import torch
+from aiohttp import web
+
+from nanofed_amd.communication import codec
+from nanofed_amd.core import ServerProtocol
+from nanofed_amd.utils import Logger, get_current_time
+
+from .types import ServerModelUpdateRequest
+
+if TYPE_CHECKING:
+    from nanofed_amd.orchestration import Coordinator
+
+_REQUIRED_UPDATE_KEYS = frozenset(
+    {"client_id", "round_number", "model_state", "metrics", "timestamp"}
+)
+
+
+@dataclass(slots=True, frozen=True)
+class ServerEndpoints:
+    get_model: str = "/model"
+    submit_update: str = "/update"
+    get_status: str = "/status"
+
+
+def _now() -> str:
+    return get_current_time().isoformat()
+
+
+def _json(payload: dict[str, Any], status: int = 200) -> web.Response:
+    return web.Response(
+        body=codec.dumps_envelope(payload),
+        status=status,
+        content_type="application/json",
+    )
+
+
+def _error(message: str, status: int) -> web.Response:
+    return _json(
+        {"status": "error", "message": message, "timestamp": _now()}, status
+    )
+
+
+class HTTPServer(ServerProtocol):
+    def __init__(
+        self,
+        host: str,
+        port: int,
+        endpoints: ServerEndpoints | None = None,
+        max_request_size: int = 100 * 1024 * 1024,
+    ) -> None:
+        self._host = host
+        self._port = port
+        self._endpoints = endpoints or ServerEndpoints()
+        self._logger = Logger()
+        self._app = web.Application(client_max_size=max_request_size)
+        self._setup_routes()
+        self._runner: web.AppRunner | None = None
+        self._site: web.TCPSite | None = None
+        self._coordinator: "Coordinator | None" = None
+
+        self._current_round: int = 0
+        self._updates: dict[str, ServerModelUpdateRequest] = {}
+        self._lock = asyncio.Lock()
+        self._is_training_done = False
+
+    # -- identity ----------------------------------------------------------
+    @property
+    def host(self) -> str:
+        return self._host
+
+    @property
+    def port(self) -> int:
+        return self._port
+
+    @property
+    def url(self) -> str:
+        return f"http://{self._host}:{self._port}"
+
+    def set_coordinator(self, coordinator: "Coordinator") -> None:
+        self._coordinator = coordinator
+
+    def advance_round(self, round_number: int) -> None:
+        """Called by the coordinator when it moves on to ``round_number``."""
+        self._current_round = int(round_number)
+
+    # -- routing -----------------------------------------------------------
+    def _setup_routes(self) -> None:
+        r = self._app.router
+        r.add_get(self._endpoints.get_model, self._handle_get_model)
+        r.add_post(self._endpoints.submit_update, self._handle_submit_update)
+        r.add_get(self._endpoints.get_status, self._handle_get_status)
+        r.add_get("/test", self._handle_test)
+
+    def _convert_tensor(self, value: Any) -> Any:
+        if isinstance(value, torch.Tensor):
+            return value.detach().cpu().tolist()
+        if isinstance(value, (list, np.ndarray)):
+            return value
+        if isinstance(value, (int, float)):
+            return [float(value)]
+        return value
+
+    async def _handle_test(self, request: web.Request) -> web.Response:
+        return web.Response(text="Server is running")
+
+    async def _handle_get_model(self, request: web.Request) -> web.Response:
+        if not self._coordinator:
+            return _error("Server not initialized with coordinator", 500)
+        with self._logger.context("server.http", "get_model"):
+            try:
+                if self._is_training_done:
+                    self._logger.info(
+                        "Training complete. Sending termination signal."
+                    )
+                    return _json(
+                        {
+                            "status": "terminated",
+                            "message": "Training is complete",
+                            "timestamp": _now(),
+                            "model_state": None,
+                            "round_number": -1,
+                        }
+                    )
+                manager = self._coordinator.model_manager
+                version = manager.current_version
+                if version is None:
+                    version = manager.load_model()
+                self._logger.debug(f"Serving model version {version.version_id}")
+                return _json(
+                    {
+                        "status": "success",
+                        "message": "Global model retrieved",
+                        "timestamp": _now(),
+                        "model_state": dict(manager.model.state_dict()),
+                        "round_number": self._current_round,
+                        "version_id": version.version_id,
+                    }
+                )
+            except Exception as exc:
+                self._logger.error(f"Error serving model: {exc}")
+                return _error(str(exc), 500)
+
+    async def _handle_submit_update(self, request: web.Request) -> web.Response:
+        with self._logger.context("server.http", "submit_update"):
+            try:
+                data = codec.loads_envelope(await request.read())
+                missing = _REQUIRED_UPDATE_KEYS - data.keys()
+                if missing:
+                    return _error(
+                        f"Missing keys: {', '.join(sorted(missing))}", 400
+                    )
+                update: ServerModelUpdateRequest = {
+                    "client_id": data["client_id"],
+                    "round_number": data["round_number"],
+                    "model_state": data["model_state"],
+                    "metrics": data["metrics"],
+                    "timestamp": data["timestamp"],
+                    "status": data.get("status", "success"),
+                    "message": data.get("message", ""),
+                    "accepted": data.get("accepted", True),
+                    "privacy_spent": data.get("privacy_spent"),
+                }
+                async with self._lock:
+                    if update["round_number"] != self._current_round:
+                        self._logger.warning(
+                            f"Update round mismatch: expected "
+                            f"{self._current_round}, got "
+                            f"{update['round_number']} from client "
+                            f"{update['client_id']}"
+                        )
+                        return _error("Invalid round number", 400)
+                    client_id = update["client_id"]
+                    self._updates[client_id] = update
+                    self._logger.info(
+                        f"Accepted update from client {client_id} for round "
+                        f"{self._current_round}"
+                    )
+                    return _json(
+                        {
+                            "status": "success",
+                            "message": "Updated accepted",
+                            "timestamp": _now(),
+                            "update_id": f"update_{client_id}_{self._current_round}",
+                            "accepted": True,
+                        }
+                    )
+            except Exception as exc:
+                self._logger.error(f"Error handling update: {exc}")
+                return _error(str(exc), 500)
+
+    async def _handle_get_status(self, request: web.Request) -> web.Response:
+        return _json(
+            {
+                "status": "success",
+                "message": "Server is running",
+                "timestamp": _now(),
+                "current_round": self._current_round,
+                "num_updates": len(self._updates),
+                "is_training_done": self._is_training_done,
+            }
+        )
+
+    # -- lifecycle -----------------------------------------------------------
+    async def stop_training(self) -> None:
+        self._is_training_done = True
+        self._logger.info(
+            "Training completed. Broadcasting termination signal to clients."
+        )
+
+    async def start(self) -> None:
+        self._logger.info("Starting HTTP server...")
+        self._runner = web.AppRunner(self._app)
+        await self._runner.setup()
+        self._site = web.TCPSite(
+            self._runner, self._host, self._port,
+            reuse_address=True, reuse_port=True,
+        )
+        await self._site.start()
+        self._logger.info(f"HTTP server started on {self._host}:{self._port}")
+
+    async def stop(self) -> None:
+        if self._site:
+            await self._site.stop()
+            self._site = None
+        if self._runner:
+            await self._runner.cleanup()
+            self._runner = None
+        self._logger.info("Server stopped")

@@ -1,0 +1,28 @@
+from .mnist import load_mnist_arrays, load_mnist_data, normalize_mnist, read_idx
+from .partition import (
+    dirichlet_partition,
+    iid_partition,
+    label_histogram,
+    sized_partition,
+)
+from .synthetic import (
+    synthetic_cifar10,
+    synthetic_images,
+    synthetic_mnist,
+    synthetic_tokens,
+)
+
+__all__ = [
+    "load_mnist_data",
+    "load_mnist_arrays",
+    "normalize_mnist",
+    "read_idx",
+    "iid_partition",
+    "sized_partition",
+    "dirichlet_partition",
+    "label_histogram",
+    "synthetic_images",
+    "synthetic_mnist",
+    "synthetic_cifar10",
+    "synthetic_tokens",
+]
