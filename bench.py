@@ -1,0 +1,128 @@
+"""Headline benchmark: federated rounds per second, MNIST-CNN FedAvg, 8 clients.
+
+One "step" is one complete federated round: broadcast of the global model,
+``local_epochs`` epochs of SGD (batch 64) on every client's 7,500-sample IID
+shard, screening, weighted FedAvg reduce (RCCL all-reduce across GPUs), new
+global model.  The 8 clients are spread over the N GPUs (8/N per GPU), so the
+total work is fixed as N grows (strong scaling).  Data is synthetic
+MNIST-shaped, weights are random-init.
+
+Reference number: 53.48 s per round = 0.0187 rounds/s (3 clients, CPU, logged
+in examples/mnist/tutorial.ipynb:523 of the reference).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+        --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+BASELINE_ROUNDS_PER_S = 1.0 / 53.48
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5, help="timed federated rounds")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed rounds")
+    ap.add_argument("--clients", type=int, default=8)
+    ap.add_argument("--local-epochs", type=int, default=2)
+    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--samples-per-client", type=int, default=7500)
+    ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "native", "torch"])
+    ap.add_argument("--model", default="mnist_cnn")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu", action="store_true", help="run on CPU/gloo (plumbing check)")
+    args = ap.parse_args()
+
+    from nanofed_amd.engine import EngineConfig, FederatedEngine
+    from nanofed_amd.parallel import Communicator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
+        return 2
+    comm = Communicator.from_env(
+        backend="gloo" if args.cpu else None, device="cpu" if args.cpu else None
+    )
+    cfg = EngineConfig(
+        model=args.model,
+        num_clients=args.clients,
+        local_epochs=args.local_epochs,
+        batch_size=args.batch_size,
+        learning_rate=args.lr,
+        samples_per_client=args.samples_per_client,
+        dtype=args.dtype,
+        backend=args.backend,
+        graph_capture=not args.no_graph,
+        eval_samples=10000,
+    )
+    engine = FederatedEngine(cfg, comm=comm)
+
+    def sync() -> None:
+        if comm.device.type == "cuda":
+            torch.cuda.synchronize(comm.device)
+
+    for _ in range(args.warmup):
+        engine.run_round()
+    comm.barrier()
+    sync()
+    t0 = time.perf_counter()
+    reports = [engine.run_round() for _ in range(args.steps)]
+    sync()
+    comm.barrier()
+    sync()
+    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
+
+    final = engine.evaluate()
+    if comm.is_root:
+        rounds_per_s = args.steps / elapsed
+        last = reports[-1] if reports else None
+        line = {
+            "metric": "federated rounds/sec (MNIST-CNN FedAvg, 8 clients)",
+            "value": rounds_per_s,
+            "unit": "rounds/s",
+            "n_gpus": comm.world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": rounds_per_s / BASELINE_ROUNDS_PER_S,
+            "dtype": args.dtype,
+            "data": "synthetic MNIST-shaped, IID shards, random-init weights",
+            "final_test_accuracy": final.get("accuracy"),
+            "final_train_accuracy": last.agg_metrics["accuracy"] if last else None,
+            "final_train_loss": last.agg_metrics["loss"] if last else None,
+            "samples_per_s": rounds_per_s
+            * args.clients * args.samples_per_client * args.local_epochs,
+            "config": {
+                "model": args.model,
+                "clients": args.clients,
+                "local_epochs": args.local_epochs,
+                "global_batch": args.batch_size * args.clients,
+                "batch_size": args.batch_size,
+                "samples_per_client": args.samples_per_client,
+                "seq_len": None,
+                "optimizer": f"SGD lr={args.lr}",
+                "backend": type(engine.trainer).__name__,
+                "parallelism": f"fed{args.clients}/gpu{comm.world_size}",
+            },
+        }
+        print(json.dumps(line), flush=True)
+    comm.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

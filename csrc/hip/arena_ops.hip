@@ -79,8 +79,9 @@ weighted_sum_kernel(float* __restrict__ out, SourceTable table,
         float4 acc = accumulate ? reinterpret_cast<const float4*>(out)[i]
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int s = 0; s < k; ++s) {
-            const float4 v = reinterpret_cast<const float4*>(table.src[s])[i];
             const float ws = w[s];
+            if (ws == 0.f) continue;  // excluded source: never read (may hold NaNs)
+            const float4 v = reinterpret_cast<const float4*>(table.src[s])[i];
             acc.x = fmaf(ws, v.x, acc.x);
             acc.y = fmaf(ws, v.y, acc.y);
             acc.z = fmaf(ws, v.z, acc.z);
@@ -93,7 +94,8 @@ weighted_sum_kernel(float* __restrict__ out, SourceTable table,
     const long t = tail0 + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t < n) {
         float acc = accumulate ? out[t] : 0.f;
-        for (int s = 0; s < k; ++s) acc = fmaf(w[s], table.src[s][t], acc);
+        for (int s = 0; s < k; ++s)
+            if (w[s] != 0.f) acc = fmaf(w[s], table.src[s][t], acc);
         out[t] = acc;
     }
 }

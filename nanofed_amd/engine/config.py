@@ -1,0 +1,71 @@
+"""Device-plane configuration.
+
+The reference configures a run through constructor dataclasses
+(``TrainingConfig`` nanofed/trainer/base.py:15-24, ``CoordinatorConfig``
+nanofed/orchestration/coordinator.py:26-49) and has no notion of devices.
+Those classes are kept as they are; the knobs that only exist on the device
+plane (clients per GPU, compute dtype, graph capture, reduce algorithm, data
+sharding, DP-SGD) live here.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Sequence
+
+
+@dataclass(frozen=True)
+class DPConfig:
+    """Per-step DP-SGD on the device (clip + Gaussian noise on gradients).
+
+    ``mode='per_sample'`` clips every example's gradient (Abadi et al.);
+    ``mode='batch'`` clips the batch-mean gradient, which is what the
+    reference's ``PrivateTrainer`` does (nanofed/trainer/private.py:54-63).
+    """
+
+    max_gradient_norm: float = 1.0
+    noise_multiplier: float = 1.1
+    epsilon: float = 10.0
+    delta: float = 1e-5
+    mode: str = "per_sample"
+
+
+@dataclass(frozen=True)
+class EngineConfig:
+    model: str = "mnist_cnn"
+    num_clients: int = 8
+    num_rounds: int = 2
+    local_epochs: int = 2
+    batch_size: int = 64
+    learning_rate: float = 0.1
+    weight_decay: float = 0.0
+    # data
+    dataset: str = "synthetic_mnist"  # synthetic_mnist | synthetic_cifar10 | synthetic_tokens | mnist
+    samples_per_client: int | Sequence[int] = 7500
+    partition: str = "iid"  # iid | dirichlet
+    dirichlet_alpha: float = 0.1
+    eval_samples: int = 10000
+    data_dir: str = "./data"
+    seq_len: int = 1024
+    # execution
+    backend: str = "auto"  # auto | native | torch
+    dtype: str = "bf16"  # compute dtype of the local trainers: bf16 | fp32
+    graph_capture: bool = True
+    reduce_algo: str = "auto"  # auto | allreduce | rs_ag
+    drop_last: bool = False
+    # quorum / robustness (reference: CoordinatorConfig.min_completion_rate)
+    min_clients: int = 1
+    min_completion_rate: float = 1.0
+    validate_updates: bool = True
+    max_update_norm: float = 0.0  # 0 disables the norm bound (finite check stays)
+    # privacy
+    dp: DPConfig | None = None
+    seed: int = 0
+    # model kwargs (e.g. GPT-2 sizes for tests)
+    model_kwargs: dict = field(default_factory=dict)
+
+    def required_clients(self) -> int:
+        """Updates needed to close a round: floor(min_clients * rate), never
+        less than one (the reference's int() can reach zero,
+        nanofed/orchestration/coordinator.py:209-211)."""
+        return max(1, int(self.min_clients * self.min_completion_rate))

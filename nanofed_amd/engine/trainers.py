@@ -1,0 +1,181 @@
+"""Local trainers of the device plane: each trains the G simulated clients
+that share one GPU for one federated round.
+
+``TorchGroupTrainer`` is the model-agnostic path.  It keeps the reference's
+training semantics (nanofed/trainer/base.py:115-198: per batch zero_grad,
+forward, cross-entropy, backward, SGD step; metrics of the last local epoch)
+but
+
+* parameters and gradients of every client are views into one arena pool, so
+  the optimizer is one multi-tensor HIP kernel per step (which also clears the
+  gradients) instead of a Python loop over tensors;
+* batches are index gathers from the HBM-resident shard, not H2D copies;
+* loss and accuracy are accumulated in a device tensor - nothing is read
+  back during the round (the reference synchronises twice per batch,
+  base.py:154,159).
+
+Forward/backward are PyTorch-ROCm ops under bf16 autocast.  The MNIST CNN has
+a fully hand-written path on top of this interface
+(``nanofed_amd.engine.mnist_native``).
+"""
+
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from nanofed_amd import ops
+from nanofed_amd.runtime.arena import ArenaPool
+
+from .config import EngineConfig
+from .data import DeviceShards
+
+# columns of the per-client metrics tensor
+M_SAMPLES, M_LOSS, M_ACC, M_VALID, M_UPDATE_SQNORM, M_EPSILON = range(6)
+METRIC_COLUMNS = 6
+
+
+def classification_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Cross-entropy over the last dimension (images: [B,C]; LM: [B,S,V])."""
+    if output.dim() > 2:
+        output = output.reshape(-1, output.shape[-1])
+        target = target.reshape(-1)
+    return F.cross_entropy(output.float(), target)
+
+
+def count_correct(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    pred = output.argmax(dim=-1)
+    return (pred == target).float().mean()
+
+
+class GroupTrainer:
+    """Interface of a per-GPU trainer."""
+
+    def train_round(self, round_idx: int) -> torch.Tensor:  # [G, METRIC_COLUMNS]
+        raise NotImplementedError
+
+    def evaluate(self, flat: torch.Tensor) -> dict[str, float]:
+        raise NotImplementedError
+
+
+class TorchGroupTrainer(GroupTrainer):
+    def __init__(
+        self,
+        cfg: EngineConfig,
+        pool: ArenaPool,
+        shards: DeviceShards,
+        model_factory: Callable[[], nn.Module],
+        eval_inputs: torch.Tensor | None = None,
+        eval_labels: torch.Tensor | None = None,
+    ) -> None:
+        self.cfg = cfg
+        self.pool = pool
+        self.shards = shards
+        self.device = pool.data.device
+        self.modules = []
+        for k in range(len(pool)):
+            m = model_factory().to(self.device)
+            m.train()
+            self.modules.append(pool[k].bind(m))
+        self._eval_module = model_factory().to(self.device)
+        self._eval_inputs = eval_inputs
+        self._eval_labels = eval_labels
+        self.metrics = torch.zeros(
+            len(pool), METRIC_COLUMNS, dtype=torch.float32, device=self.device
+        )
+        self._acc = torch.zeros(len(pool), 3, dtype=torch.float32, device=self.device)
+        self._amp = cfg.dtype == "bf16" and self.device.type == "cuda"
+        self._dp_step = 0
+
+    # -- one optimisation step of client k --------------------------------
+    def _step(self, k: int, rows: torch.Tensor) -> None:
+        cfg = self.cfg
+        module = self.modules[k]
+        arena = self.pool[k]
+        x, y = self.shards.batch(rows)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self._amp):
+            out = module(x)
+            loss = classification_loss(out, y)
+        loss.backward()
+        if cfg.dp is not None:
+            self._privatise(k, int(rows.numel()))
+        ops.sgd_step(
+            arena.trainable, arena.grad, cfg.learning_rate, cfg.weight_decay,
+            zero_grad=True,
+        )
+        acc = self._acc[k]
+        acc[0] += loss.detach()
+        acc[1] += count_correct(out.detach(), y)
+        acc[2] += 1.0
+
+    def _privatise(self, k: int, batch: int) -> None:
+        """Batch-level clip + Gaussian noise on the gradient arena - the
+        reference's DP step (nanofed/trainer/private.py:54-86) as two fused
+        passes over one buffer."""
+        dp = self.cfg.dp
+        g = self.pool[k].grad
+        cid = self.shards.client_ids[k]
+        self._dp_step += 1
+        ops.clip_noise(
+            g, dp.max_gradient_norm, dp.noise_multiplier * dp.max_gradient_norm,
+            seed=self.cfg.seed * 2654435761 + cid, offset=self._dp_step, out=g,
+        )
+
+    def train_round(self, round_idx: int) -> torch.Tensor:
+        cfg = self.cfg
+        G = len(self.pool)
+        self.metrics.zero_()
+        for k in range(G):
+            for epoch in range(cfg.local_epochs):
+                self._acc[k].zero_()
+                perm = self.shards.epoch_permutation(k, round_idx, epoch)
+                steps = self.shards.steps_per_epoch(k)
+                for s in range(steps):
+                    rows = perm[s * cfg.batch_size : (s + 1) * cfg.batch_size]
+                    self._step(k, rows)
+            batches = self._acc[k, 2].clamp(min=1.0)
+            self.metrics[k, M_SAMPLES] = float(self.shards.sizes[k])
+            self.metrics[k, M_LOSS] = self._acc[k, 0] / batches
+            self.metrics[k, M_ACC] = self._acc[k, 1] / batches
+            self.metrics[k, M_VALID] = 1.0
+            self.pool[k].pull_int_buffers(self.modules[k])
+        return self.metrics
+
+    # -- held-out evaluation (absent from the reference: TrainerProtocol.validate
+    #    is declared in nanofed/core/interfaces.py:33 and never implemented) ----
+    @torch.no_grad()
+    def evaluate(self, flat: torch.Tensor, batch: int = 1000) -> dict[str, float]:
+        from nanofed_amd.runtime.arena import ParameterArena
+
+        if self._eval_inputs is None:
+            return {}
+        arena = ParameterArena(self.pool.layout, data=flat)
+        module = arena.bind(self._eval_module)
+        arena.push_int_buffers(module)
+        module.eval()
+        xs = self._eval_inputs.to(self.device)
+        ys = self._eval_labels.to(self.device) if self._eval_labels is not None else None
+        loss_sum = torch.zeros((), device=self.device)
+        correct = torch.zeros((), device=self.device)
+        n = 0
+        for lo in range(0, len(xs), batch):
+            if self.shards.kind == "image":
+                x = xs[lo : lo + batch].float().div_(255.0)
+                x = x.sub_(self.shards.mean).div_(self.shards.std)
+                y = ys[lo : lo + batch]
+            else:
+                x, y = xs[lo : lo + batch, :-1], xs[lo : lo + batch, 1:]
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self._amp):
+                out = module(x)
+            m = len(x)
+            loss_sum += classification_loss(out, y) * m
+            correct += count_correct(out, y) * m
+            n += m
+        return {
+            "loss": float(loss_sum) / max(n, 1),
+            "accuracy": float(correct) / max(n, 1),
+            "samples": float(n),
+        }

@@ -35,9 +35,9 @@ def hip_lib() -> ctypes.CDLL:
     return lib
 
 
-def _declare(lib: ctypes.CDLL) -> None:
+def _signatures() -> dict:
     P, L, I, F, U = c_void_p, c_long, c_int, c_float, c_ulonglong
-    sigs = {
+    return {
         "nf_max_sources": ([], I),
         "nf_reduce_workspace_floats": ([], I),
         "nf_weighted_sum": ([P, P, P, I, L, I, P], I),
@@ -47,12 +47,25 @@ def _declare(lib: ctypes.CDLL) -> None:
         "nf_philox_fill": ([P, L, U, U, L, I, F, I, P], I),
         "nf_scale_accumulate": ([P, P, L, F, F, P], I),
     }
-    for name, (argtypes, restype) in sigs.items():
+
+
+def _declare(lib: ctypes.CDLL) -> None:
+    for name, (argtypes, restype) in _signatures().items():
         fn = getattr(lib, name, None)
         if fn is None:
             continue
         fn.argtypes = argtypes
         fn.restype = restype
+
+
+def hip_lib_symbols_check() -> list[str]:
+    """Load the HIP library and make sure every declared launcher is exported
+    (the build check: works without a GPU)."""
+    lib = hip_lib()
+    missing = [n for n in _signatures() if getattr(lib, n, None) is None]
+    if missing:
+        raise DeviceError(f"libnanofed_hip.so lacks symbols: {missing}")
+    return sorted(_signatures())
 
 
 def declare(name: str, argtypes: list, restype=c_int):
