@@ -1,0 +1,806 @@
+// Hand-written gfx950 training step of the MNIST CNN
+//   conv1 1->32 k3, ReLU, conv2 32->64 k3, ReLU, maxpool2, dropout(.25),
+//   fc1 9216->128, ReLU, dropout(.5), fc2 128->10, log-softmax + NLL
+// (reference model: nanofed/models/mnist.py:6-28; loss: nanofed/trainer/torch.py:14;
+//  step: nanofed/trainer/base.py:141-159) for the G simulated clients that share
+// one GPU, all of them in every launch (blockIdx.y = client).
+//
+// One optimisation step is ten launches, none of which synchronises with the
+// host; dropout offsets come from a device-side step counter, batch rows from
+// a device index table, so a whole epoch can be recorded in one hipGraph.
+//
+//   conv1_fwd      direct 3x3 conv on the uint8 dataset rows (gather + normalise
+//                  fused), ReLU, bf16 NHWC out
+//   conv2_fwd      implicit GEMM on MFMA 32x32x16 bf16, weights stationary in
+//                  registers, activations staged through LDS; bias + ReLU +
+//                  2x2 max-pool + dropout in the epilogue (pooling is register
+//                  local thanks to a window-major row order); writes pooled
+//                  activations and a 1-byte argmax/alive code
+//   fc1_fwd        split-K MFMA GEMM, operands streamed straight to registers,
+//                  fp32 partial slabs (deterministic reduction)
+//   head           slab reduce + bias + ReLU + dropout, fc2, log-softmax, NLL,
+//                  accuracy, d(logits), fc2 backward, d(h1)  - one launch
+//   fc1_wgrad      dW1 = dh1^T p2, both operands transposed on the fly with
+//                  ds_read_b64_tr_b16
+//   fc1_dgrad      dp2 = dh1 W1 (W1 tile transposed by LDS tr-reads), fused with
+//                  dropout/max-pool/ReLU backward: scatters to d(conv2 out)
+//   conv2_dgrad    implicit GEMM (K = 9 taps x 64), zero-halo LDS patch with XOR
+//                  swizzle; epilogue applies conv1's ReLU mask and reduces
+//                  conv1's weight/bias gradient, so d(a1) never reaches memory
+//   conv2_wgrad    pixels are the reduction dimension of both operands:
+//                  tr-reads for both; fp32 partial tiles per workgroup
+//   finalize       fixed-order sum of all partial slabs into the gradient arena,
+//                  loss/accuracy accumulation
+//   sgd_pack       SGD on the flat arena + bf16 shadow + transposed conv2 shadow
+//
+// Storage ("native") layout of the parameters: conv2.weight [oc][kh][kw][c],
+// fc1.weight [j][(ph*12+pw)*64 + c]; everything else as in PyTorch.
+// Batch size is 64 (two 32-row MFMA blocks).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../common/philox.h"
+#include "nf_device.h"
+
+using namespace nfd;
+
+extern "C" {
+
+struct MnistCtx {
+    int G, B, S, WPC;
+    int train;            // 1: dropout active
+    int client_base;      // global id of client 0 (dropout streams)
+    int pad0, pad1;
+    const uint8_t* images;  // [N][784]
+    const int32_t* labels;  // [N]
+    const int32_t* idx;     // [G][idx_stride] dataset rows of every step
+    long idx_stride;
+    const int32_t* nvalid;  // [G][nvalid_stride] valid samples per step
+    long nvalid_stride;
+    float* arena;           // [G][arena_stride] fp32 master parameters
+    long arena_stride;
+    float* grad;            // [G][grad_stride]
+    long grad_stride;
+    bf16* shadow;           // [G][shadow_stride] bf16 copy of the arena
+    long shadow_stride;
+    bf16* w2t;              // [G][w2t_stride] conv2 weights as [tap][c][oc]
+    long w2t_stride;
+    long n_arena;
+    int off_c1w, off_c1b, off_c2w, off_c2b, off_f1w, off_f1b, off_f2w, off_f2b;
+    bf16* a1;               // [G][B][676][32]
+    bf16* p2;               // [G][B][144][64]
+    uint8_t* pmask;         // [G][B][144][64] bits 0-1 argmax, bit 2 alive
+    float* fc1_slabs;       // [G][S][B][128]
+    bf16* dh1;              // [G][B][128]
+    bf16* da2;              // [G][B][576][64]
+    float* conv1_part;      // [G][B][320]
+    float* conv2_part;      // [G][WPC][18496]
+    float* head_part;       // [G][B/16][1440]
+    float* metrics;         // [G][4] loss sum, accuracy sum, batches, -
+    float* eval_out;        // [2] loss sum, correct count (eval mode)
+    unsigned long long* step_counter;
+    unsigned long long seed;
+    float lr, wd, mean, inv_std, p_drop1, p_drop2;
+};
+
+}  // extern "C"
+
+namespace {
+
+constexpr int kA1Pix = 676, kA1C = 32, kP2Pix = 144, kC2 = 64, kFc1K = 9216;
+constexpr int kHeadPart = 1440, kConv2Part = 18496, kConv1Part = 320;
+
+__device__ __forceinline__ unsigned long long client_seed(const MnistCtx& c, int g) {
+    return c.seed + 0x9E3779B97F4A7C15ull * static_cast<unsigned long long>(c.client_base + g + 1);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off) {
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    __shared__ float xs[784];
+    __shared__ float ws[288];
+    __shared__ float bs[32];
+    const int row = c.idx[g * c.idx_stride + idx_off + b];
+    const uint8_t* img = c.images + static_cast<long>(row) * 784;
+    if (tid < 196) {
+        const uchar4 v = reinterpret_cast<const uchar4*>(img)[tid];
+        const float k = 1.0f / 255.0f;
+        xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
+        xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
+        xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
+        xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
+    }
+    const float* wa = c.arena + g * c.arena_stride;
+    for (int i = tid; i < 288; i += 256) ws[i] = wa[c.off_c1w + i];
+    if (tid < 32) bs[tid] = wa[c.off_c1b + tid];
+    __syncthreads();
+
+    bf16* out = c.a1 + (static_cast<long>(g) * c.B + b) * (kA1Pix * kA1C);
+    for (int task = tid; task < kA1Pix * 4; task += 256) {
+        const int px = task >> 2, cg = task & 3;
+        const int y = px / 26, x = px - y * 26;
+        float xv[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xs[(y + kh) * 28 + x + kw];
+        bf16x8 o;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int ch = cg * 8 + cc;
+            float acc = bs[ch];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = fmaf(ws[ch * 9 + t], xv[t], acc);
+            o[cc] = f2bf(fmaxf(acc, 0.f));
+        }
+        *reinterpret_cast<bf16x8*>(out + px * kA1C + cg * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kFwdPitch = 80;  // 64 B of channels + 16 B pad per pixel
+constexpr int kFwdLds = 260 * kFwdPitch;
+
+__global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nb = wave & 1, mgrp = wave >> 1;
+    const int n = lane & 31, h = lane >> 5;
+
+    // stationary operand: this wave's 32 output channels, all of K = 9 x 32
+    const bf16* w = c.shadow + g * c.shadow_stride + c.off_c2w +
+                    static_cast<long>(nb * 32 + n) * 288;
+    bf16x8 Bf[18];
+#pragma unroll
+    for (int s = 0; s < 18; ++s)
+        Bf[s] = *reinterpret_cast<const bf16x8*>(w + (s >> 1) * 32 + (s & 1) * 16 + 8 * h);
+    const float bias = (c.arena + g * c.arena_stride)[c.off_c2b + nb * 32 + n];
+
+    // row m of a 32-pixel block is position q of pooling window wi (m = 4*wi + q)
+    const int wi = n >> 2, q = n & 3;
+    const int dy = 2 * (wi >> 2) + (q >> 1), dx = 2 * (wi & 3) + (q & 1);
+
+    const bf16* a1img = c.a1 + (static_cast<long>(g) * c.B + b) * (kA1Pix * kA1C);
+    const long out_img = (static_cast<long>(g) * c.B + b) * kP2Pix;
+    const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
+    const unsigned long long ctr = c.train ? *c.step_counter : 0ull;
+    const unsigned long long seed = client_seed(c, g);
+
+    for (int band = 0; band < 3; ++band) {
+        __syncthreads();
+        const uint4* src = reinterpret_cast<const uint4*>(a1img + band * 8 * 26 * kA1C);
+        for (int p = tid; p < 1040; p += 256)
+            *reinterpret_cast<uint4*>(smem + (p >> 2) * kFwdPitch + (p & 3) * 16) = src[p];
+        __syncthreads();
+
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+            const int mbi = mgrp * 3 + i;
+            const int by = mbi / 3, bx = mbi - by * 3;
+            const int oy = by * 4 + dy, ox = bx * 8 + dx;
+            const char* abase = smem + (oy * 26 + ox) * kFwdPitch + h * 16;
+            f32x16 acc = {0};
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                const int tap = s >> 1, kh = tap / 3, kw = tap - kh * 3;
+                const bf16x8 A = *reinterpret_cast<const bf16x8*>(
+                    abase + (kh * 26 + kw) * kFwdPitch + (s & 1) * 32);
+                acc = mfma32(A, Bf[s], acc);
+            }
+            float u[4] = {1.f, 1.f, 1.f, 1.f};
+            if (c.train) {
+                const unsigned long long blk =
+                    ((static_cast<unsigned long long>(b) * 3 + band) * 6 + mbi) * 64 + nb * 32 + n;
+                nf::philox_samples(seed, 2 * ctr, blk, 0, u);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float best = acc[4 * rg] + bias;
+                int am = 0;
+#pragma unroll
+                for (int qq = 1; qq < 4; ++qq) {
+                    const float v = acc[4 * rg + qq] + bias;
+                    if (v > best) { best = v; am = qq; }
+                }
+                bool alive = best > 0.f;
+                if (c.train) alive = alive && (u[rg] >= c.p_drop1);
+                const float val = alive ? best * keep_scale : 0.f;
+                const int ph = band * 4 + by * 2 + (rg >> 1);
+                const int pw = bx * 4 + 2 * (rg & 1) + h;
+                const long o = (out_img + ph * 12 + pw) * kC2 + nb * 32 + n;
+                c.p2[o] = f2bf(val);
+                c.pmask[o] = static_cast<uint8_t>(am | (alive ? 4 : 0));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
+    const int kc = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int KC = kFc1K / c.S;
+    const bf16* A0 = c.p2 + (static_cast<long>(g) * c.B + n) * kFc1K + kc * KC + 8 * h;
+    const bf16* A1 = A0 + 32 * kFc1K;
+    const bf16* Bp = c.shadow + g * c.shadow_stride + c.off_f1w +
+                     static_cast<long>(wave * 32 + n) * kFc1K + kc * KC + 8 * h;
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll 8
+    for (int k = 0; k < KC; k += 16) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A0 + k);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A1 + k);
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Bp + k);
+        acc0 = mfma32(a0, bb, acc0);
+        acc1 = mfma32(a1, bb, acc1);
+    }
+    float* out = c.fc1_slabs + ((static_cast<long>(g) * c.S + kc) * c.B) * 128 + wave * 32 + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        out[row * 128] = acc0[r];
+        out[(row + 32) * 128] = acc1[r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int step) {
+    const int hb = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    __shared__ float h1s[16][129];
+    __shared__ float dm[16][129];
+    __shared__ float w2[10][129];
+    __shared__ float lg[16][12];
+    __shared__ float dl[16][12];
+    __shared__ float red[2][16];
+    const int r0 = hb * 16;
+    const float* wa = c.arena + g * c.arena_stride;
+    for (int i = tid; i < 1280; i += 256) w2[i >> 7][i & 127] = wa[c.off_f2w + i];
+
+    // A: reduce the split-K slabs, bias, ReLU, dropout
+    const int r = tid >> 4, j0 = (tid & 15) * 8;
+    const int b = r0 + r;
+    {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = wa[c.off_f1b + j0 + e];
+        for (int s = 0; s < c.S; ++s) {
+            const float4* p = reinterpret_cast<const float4*>(
+                c.fc1_slabs + ((static_cast<long>(g) * c.S + s) * c.B + b) * 128 + j0);
+            const float4 v0 = p[0], v1 = p[1];
+            acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+            acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+        }
+        float u[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        float sc = 1.0f;
+        if (c.train) {
+            const unsigned long long ctr = *c.step_counter;
+            const unsigned long long blk = (static_cast<unsigned long long>(b) * 128 + j0) >> 2;
+            nf::philox_samples(client_seed(c, g), 2 * ctr + 1, blk, 0, u);
+            nf::philox_samples(client_seed(c, g), 2 * ctr + 1, blk + 1, 0, u + 4);
+            sc = 1.0f / (1.0f - c.p_drop2);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bool alive = acc[e] > 0.f;
+            if (c.train) alive = alive && (u[e] >= c.p_drop2);
+            h1s[r][j0 + e] = alive ? acc[e] * sc : 0.f;
+            dm[r][j0 + e] = alive ? sc : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // B: logits
+    if (tid < 160) {
+        const int rr = tid / 10, o = tid - rr * 10;
+        float acc = wa[c.off_f2b + o];
+#pragma unroll 8
+        for (int j = 0; j < 128; ++j) acc = fmaf(h1s[rr][j], w2[o][j], acc);
+        lg[rr][o] = acc;
+    }
+    __syncthreads();
+
+    // C: log-softmax, NLL, accuracy, d(logits)
+    const int nv = c.nvalid[g * c.nvalid_stride + step];
+    if (tid < 16) {
+        const int bb = r0 + tid;
+        const bool valid = bb < nv;
+        const int y = c.labels[c.idx[g * c.idx_stride + idx_off + bb]];
+        float m = lg[tid][0];
+        int pred = 0;
+        for (int o = 1; o < 10; ++o)
+            if (lg[tid][o] > m) { m = lg[tid][o]; pred = o; }
+        float se = 0.f;
+        for (int o = 0; o < 10; ++o) se += __expf(lg[tid][o] - m);
+        const float lse = m + __logf(se);
+        const float inv = nv > 0 ? 1.0f / static_cast<float>(nv) : 0.f;
+        for (int o = 0; o < 10; ++o) {
+            const float p = __expf(lg[tid][o] - lse);
+            dl[tid][o] = valid ? (p - (o == y ? 1.f : 0.f)) * inv : 0.f;
+        }
+        red[0][tid] = valid ? (lse - lg[tid][y]) : 0.f;
+        red[1][tid] = (valid && pred == y) ? 1.f : 0.f;
+    }
+    __syncthreads();
+
+    float loss_sum = 0.f, correct = 0.f;
+    if (tid == 0) {
+        for (int i = 0; i < 16; ++i) { loss_sum += red[0][i]; correct += red[1][i]; }
+    }
+    if (!c.train && c.eval_out != nullptr) {
+        if (tid == 0) {
+            atomicAdd(c.eval_out + 0, loss_sum);
+            atomicAdd(c.eval_out + 1, correct);
+        }
+        return;
+    }
+
+    float* part = c.head_part + (static_cast<long>(g) * (c.B / 16) + hb) * kHeadPart;
+    // D: fc2 weight / bias gradient (partial over this block's 16 rows)
+    for (int i = tid; i < 1280; i += 256) {
+        const int o = i >> 7, j = i & 127;
+        float acc = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc = fmaf(dl[rr][o], h1s[rr][j], acc);
+        part[i] = acc;
+    }
+    if (tid < 10) {
+        float acc = 0.f;
+        for (int rr = 0; rr < 16; ++rr) acc += dl[rr][tid];
+        part[1280 + tid] = acc;
+    }
+    // E: d(h1 pre-activation)
+    {
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int o = 0; o < 10; ++o) v = fmaf(dl[r][o], w2[o][j0 + e], v);
+            v *= dm[r][j0 + e];
+            dm[r][j0 + e] = v;
+            o8[e] = f2bf(v);
+        }
+        *reinterpret_cast<bf16x8*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o8;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float acc = 0.f;
+        for (int rr = 0; rr < 16; ++rr) acc += dm[rr][tid];
+        part[1296 + tid] = acc;
+    }
+    if (tid == 0) { part[1424] = loss_sum; part[1425] = correct; }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kTrPitch128 = 320;  // 256 B of data + 64 B: 4 consecutive k rows hit distinct banks
+
+__global__ void __launch_bounds__(256) fc1_wgrad_kernel(MnistCtx c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_dh = smem;                    // [64 b][128 j]
+    char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
+    const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31;
+    const bf16* dh = c.dh1 + static_cast<long>(g) * c.B * 128;
+    const bf16* p2 = c.p2 + static_cast<long>(g) * c.B * kFc1K + tile * 128;
+    for (int p = tid; p < 1024; p += 256) {
+        const int row = p >> 4, part = p & 15;
+        *reinterpret_cast<uint4*>(s_dh + row * kTrPitch128 + part * 16) =
+            *reinterpret_cast<const uint4*>(dh + row * 128 + part * 8);
+        *reinterpret_cast<uint4*>(s_p2 + row * kTrPitch128 + part * 16) =
+            *reinterpret_cast<const uint4*>(p2 + static_cast<long>(row) * kFc1K + part * 8);
+    }
+    __syncthreads();
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 Bfr = load_tr_frag(s_p2, kTrPitch128, ks * 16, wave * 32, lane);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const bf16x8 Afr = load_tr_frag(s_dh, kTrPitch128, ks * 16, mb * 32, lane);
+            acc[mb] = mfma32(Afr, Bfr, acc[mb]);
+        }
+    }
+    float* gr = c.grad + g * c.grad_stride + c.off_f1w + tile * 128 + wave * 32 + n;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            gr[static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K] = acc[mb][r];
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [128 j][128 k'] pitch 320
+    const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const bf16* w = c.shadow + g * c.shadow_stride + c.off_f1w + tile * 128;
+    for (int p = tid; p < 2048; p += 256) {
+        const int row = p >> 4, part = p & 15;
+        *reinterpret_cast<uint4*>(smem + row * kTrPitch128 + part * 16) =
+            *reinterpret_cast<const uint4*>(w + static_cast<long>(row) * kFc1K + part * 8);
+    }
+    const bf16* dh = c.dh1 + static_cast<long>(g) * c.B * 128 + 8 * h;
+    bf16x8 Af[2][8];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            Af[mb][ks] = *reinterpret_cast<const bf16x8*>(dh + (mb * 32 + n) * 128 + ks * 16);
+    __syncthreads();
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 Bfr = load_tr_frag(smem, kTrPitch128, ks * 16, wave * 32, lane);
+        acc0 = mfma32(Af[0][ks], Bfr, acc0);
+        acc1 = mfma32(Af[1][ks], Bfr, acc1);
+    }
+    // dropout / max-pool / ReLU backward: route to the arg-max position
+    const int pp = tile * 2 + (wave >> 1), ch = (wave & 1) * 32 + n;
+    const int ph = pp / 12, pw = pp - ph * 12;
+    const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
+    const bf16 zero = f2bf(0.f);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = mb * 32 + acc_row(r, lane);
+            const long img = static_cast<long>(g) * c.B + b;
+            const uint8_t m = c.pmask[(img * kP2Pix + pp) * kC2 + ch];
+            const float v = (mb == 0 ? acc0[r] : acc1[r]) * ((m & 4) ? keep_scale : 0.f);
+            const bf16 vb = f2bf(v);
+            const int am = m & 3;
+            bf16* d = c.da2 + ((img * 576 + (2 * ph) * 24 + 2 * pw) * kC2 + ch);
+            d[0] = am == 0 ? vb : zero;
+            d[kC2] = am == 1 ? vb : zero;
+            d[24 * kC2] = am == 2 ? vb : zero;
+            d[25 * kC2] = am == 3 ? vb : zero;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kDgPatchRows = 13, kDgPatchCols = 28;
+constexpr int kDgPatchBytes = kDgPatchRows * kDgPatchCols * 128;  // 46592
+constexpr int kDgLds = kDgPatchBytes + 784 * 4 + 4 * 32 * 10 * 4;
+
+__device__ __forceinline__ int dg_swz(int pi, int part) {
+    return pi * 128 + ((part ^ ((pi >> 1) & 7)) << 4);
+}
+
+__global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);
+    float* red = xs + 784;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const long img = static_cast<long>(g) * c.B + b;
+
+    // stationary operand: W2 as [k = (tap, oc)][col = c]
+    const bf16* wt = c.w2t + g * c.w2t_stride + n * 64 + 8 * h;
+    bf16x8 Bf[36];
+#pragma unroll
+    for (int ks = 0; ks < 36; ++ks)
+        Bf[ks] = *reinterpret_cast<const bf16x8*>(wt + (ks >> 2) * (32 * 64) + (ks & 3) * 16);
+
+    {
+        const int row = c.idx[g * c.idx_stride + idx_off + b];
+        const uint8_t* im = c.images + static_cast<long>(row) * 784;
+        if (tid < 196) {
+            const uchar4 v = reinterpret_cast<const uchar4*>(im)[tid];
+            const float k = 1.0f / 255.0f;
+            xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
+            xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
+            xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
+            xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
+        }
+    }
+    float cw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float cb = 0.f;
+    const bf16* da2 = c.da2 + img * 576 * kC2;
+    const bf16* a1 = c.a1 + img * kA1Pix * kA1C;
+
+    for (int chunk = 0; chunk < 3; ++chunk) {
+        const int mb0 = chunk * 8;
+        const int nmb = chunk < 2 ? 8 : 6;
+        const int pix0 = mb0 * 32;
+        const int pixl = min(pix0 + nmb * 32, kA1Pix) - 1;
+        const int ymin = pix0 / 26, ymax = pixl / 26;
+        const int oy_base = ymin - 2;
+        const int nrows = ymax - ymin + 3;
+        __syncthreads();
+        for (int p = tid; p < nrows * kDgPatchCols * 8; p += 256) {
+            const int pi = p >> 3, part = p & 7;
+            const int pr = pi / kDgPatchCols, pc = pi - pr * kDgPatchCols;
+            const int oy = oy_base + pr, ox = pc - 2;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (oy >= 0 && oy < 24 && ox >= 0 && ox < 24)
+                v = *reinterpret_cast<const uint4*>(da2 + (oy * 24 + ox) * kC2 + part * 8);
+            *reinterpret_cast<uint4*>(smem + dg_swz(pi, part)) = v;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const int mb = mb0 + wave * 2 + i;
+            if (mb >= mb0 + nmb) break;  // wave-uniform
+            const int p = min(mb * 32 + n, kA1Pix - 1);
+            const int y = p / 26, x = p - y * 26;
+            const int pi0 = (y - oy_base) * kDgPatchCols + x + 2;
+            f32x16 acc = {0};
+#pragma unroll
+            for (int ks = 0; ks < 36; ++ks) {
+                const int tap = ks >> 2, kh = tap / 3, kw = tap - kh * 3;
+                const int pi = pi0 - kh * kDgPatchCols - kw;
+                const bf16x8 A = *reinterpret_cast<const bf16x8*>(
+                    smem + dg_swz(pi, (ks & 3) * 2 + h));
+                acc = mfma32(A, Bf[ks], acc);
+            }
+            // ReLU mask of conv1's output, then conv1's weight gradient
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = mb * 32 + acc_row(r, lane);
+                if (pp < kA1Pix) {
+                    const float a = bf2f(a1[pp * kA1C + n]);
+                    const float d = a > 0.f ? acc[r] : 0.f;
+                    const int yy = pp / 26, xx = pp - yy * 26;
+                    cb += d;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            cw[kh * 3 + kw] = fmaf(d, xs[(yy + kh) * 28 + xx + kw], cw[kh * 3 + kw]);
+                }
+            }
+        }
+    }
+    // combine the two lane halves (same channel), then the four waves
+#pragma unroll
+    for (int t = 0; t < 9; ++t) cw[t] += __shfl_xor(cw[t], 32, 64);
+    cb += __shfl_xor(cb, 32, 64);
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[(wave * 32 + n) * 10 + t] = cw[t];
+        red[(wave * 32 + n) * 10 + 9] = cb;
+    }
+    __syncthreads();
+    if (tid < 320) {
+        const int ch = tid / 10, t = tid - ch * 10;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += red[(w * 32 + ch) * 10 + t];
+        float* part = c.conv1_part + img * kConv1Part;
+        if (t < 9) part[ch * 9 + t] = s;
+        else part[288 + ch] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kWgDaPitch = 192;  // 128 B of channels + 64 B
+constexpr int kWgDaBytes = 192 * kWgDaPitch;  // 36864
+constexpr int kWgA1Bytes = 260 * 64;          // 16640
+constexpr int kWgLds = kWgDaBytes + kWgA1Bytes + 6 * 64 * 4;
+
+__global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_da = smem;               // [192 px][64 oc], pitch 192
+    char* s_a1 = smem + kWgDaBytes;  // [260 px][32 c], pitch 64
+    float* red = reinterpret_cast<float*>(smem + kWgDaBytes + kWgA1Bytes);
+    const int wg = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int ocb = wave & 1, tg = wave >> 1;
+    const int ipw = c.B / c.WPC;
+    f32x16 acc[3] = {{0}, {0}, {0}};
+    float bsum = 0.f;
+    // per-lane pieces of the tap-shifted transposed read (see load_tr_frag)
+    const int li = lane & 15;
+    const int lq = li >> 2;
+    const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+
+    for (int im = wg * ipw; im < (wg + 1) * ipw; ++im) {
+        const long img = static_cast<long>(g) * c.B + im;
+        for (int band = 0; band < 3; ++band) {
+            __syncthreads();
+            const uint4* sda = reinterpret_cast<const uint4*>(c.da2 + (img * 576 + band * 192) * kC2);
+            for (int p = tid; p < 1536; p += 384)
+                *reinterpret_cast<uint4*>(s_da + (p >> 3) * kWgDaPitch + (p & 7) * 16) = sda[p];
+            const uint4* sa1 = reinterpret_cast<const uint4*>(
+                c.a1 + (img * kA1Pix + band * 8 * 26) * kA1C);
+            for (int p = tid; p < 1040; p += 384)
+                *reinterpret_cast<uint4*>(s_a1 + p * 16) = sa1[p];
+            __syncthreads();
+            {
+                const int oc = tid & 63, strip = tid >> 6;
+                for (int px = strip * 32; px < strip * 32 + 32; ++px)
+                    bsum += bf2f(*reinterpret_cast<const bf16*>(s_da + px * kWgDaPitch + oc * 2));
+            }
+#pragma unroll 2
+            for (int ks = 0; ks < 12; ++ks) {
+                const bf16x8 Afr = load_tr_frag(s_da, kWgDaPitch, ks * 16, ocb * 32, lane);
+                // the 8 pixels of this lane half: groups gi0, gi0 + 1 of 4 pixels
+                const int gi0 = 4 * ks + 2 * h;
+                const int oy0 = gi0 / 6, ox0 = 4 * (gi0 - oy0 * 6);
+                const int gi1 = gi0 + 1;
+                const int oy1 = gi1 / 6, ox1 = 4 * (gi1 - oy1 * 6);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int tap = tg * 3 + t;  // kh = tg, kw = t
+                    const bf16x4 lo = lds_tr4(s_a1 + ((oy0 + tg) * 26 + ox0 + t + lq) * 64 + lcol);
+                    const bf16x4 hi = lds_tr4(s_a1 + ((oy1 + tg) * 26 + ox1 + t + lq) * 64 + lcol);
+                    (void)tap;
+                    const bf16x8 Bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = mfma32(Afr, Bfr, acc[t]);
+                }
+            }
+        }
+    }
+    float* part = c.conv2_part + (static_cast<long>(g) * c.WPC + wg) * kConv2Part;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tap = tg * 3 + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = ocb * 32 + acc_row(r, lane);
+            part[(oc * 9 + tap) * 32 + n] = acc[t][r];
+        }
+    }
+    __syncthreads();
+    red[(tid >> 6) * 64 + (tid & 63)] = bsum;
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int st = 0; st < 6; ++st) s += red[st * 64 + tid];
+        part[18432 + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kSmallTotal = kConv1Part + kConv2Part + kHeadPart;
+
+__global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
+    const int g = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kSmallTotal) return;
+    float* gr = c.grad + g * c.grad_stride;
+    if (e < kConv1Part) {
+        const float* p = c.conv1_part + static_cast<long>(g) * c.B * kConv1Part + e;
+        float s = 0.f;
+        for (int b = 0; b < c.B; ++b) s += p[static_cast<long>(b) * kConv1Part];
+        if (e < 288) gr[c.off_c1w + e] = s;
+        else gr[c.off_c1b + e - 288] = s;
+    } else if (e < kConv1Part + kConv2Part) {
+        const int e2 = e - kConv1Part;
+        const float* p = c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2;
+        float s = 0.f;
+        for (int w = 0; w < c.WPC; ++w) s += p[static_cast<long>(w) * kConv2Part];
+        if (e2 < 18432) gr[c.off_c2w + e2] = s;
+        else gr[c.off_c2b + e2 - 18432] = s;
+    } else {
+        const int e3 = e - kConv1Part - kConv2Part;
+        const int hbn = c.B / 16;
+        const float* p = c.head_part + static_cast<long>(g) * hbn * kHeadPart + e3;
+        float s = 0.f;
+        for (int hb = 0; hb < hbn; ++hb) s += p[static_cast<long>(hb) * kHeadPart];
+        if (e3 < 1280) gr[c.off_f2w + e3] = s;
+        else if (e3 < 1290) gr[c.off_f2b + e3 - 1280] = s;
+        else if (e3 >= 1296 && e3 < 1424) gr[c.off_f1b + e3 - 1296] = s;
+        else if (e3 == 1424 || e3 == 1425) {
+            const int nv = c.nvalid[g * c.nvalid_stride + step];
+            if (nv > 0) {
+                float* m = c.metrics + g * 4;
+                if (e3 == 1424) { m[0] += s / nv; m[2] += 1.0f; }
+                else m[1] += s / nv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// force = 1: refresh the bf16 copies only (lr is ignored, nothing is skipped,
+// the step counter stays).
+__global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int force) {
+    const int g = blockIdx.y;
+    if (!force && g == 0 && blockIdx.x == 0 && threadIdx.x == 0) *c.step_counter += 1ull;
+    float lr = c.lr, wd = c.wd;
+    if (force) { lr = 0.f; wd = 0.f; }
+    else if (c.nvalid[g * c.nvalid_stride + step] == 0) return;  // client has no batch left
+    float* p = c.arena + g * c.arena_stride;
+    const float* gr = c.grad + g * c.grad_stride;
+    bf16* sh = c.shadow + g * c.shadow_stride;
+    bf16* w2t = c.w2t + g * c.w2t_stride;
+    const long n4 = c.n_arena >> 2;
+    for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4;
+         i += static_cast<long>(gridDim.x) * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        if (!force) {
+            const float4 gv = reinterpret_cast<const float4*>(gr)[i];
+            pv.x -= lr * fmaf(wd, pv.x, gv.x);
+            pv.y -= lr * fmaf(wd, pv.y, gv.y);
+            pv.z -= lr * fmaf(wd, pv.z, gv.z);
+            pv.w -= lr * fmaf(wd, pv.w, gv.w);
+            reinterpret_cast<float4*>(p)[i] = pv;
+        }
+        bf16x4 hv;
+        hv[0] = f2bf(pv.x); hv[1] = f2bf(pv.y); hv[2] = f2bf(pv.z); hv[3] = f2bf(pv.w);
+        reinterpret_cast<bf16x4*>(sh)[i] = hv;
+        const long base = i << 2;
+        if (base >= c.off_c2w && base < c.off_c2w + 18432) {
+            const int e = static_cast<int>(base - c.off_c2w);  // 4 consecutive c of one (oc, tap)
+            const int oc = e / 288, r = e - oc * 288;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w2t[(r + q) * 64 + oc] = hv[q];
+        }
+    }
+}
+
+inline int check_ctx(const MnistCtx* c) {
+    if (c->B != 64) return -2;
+    if (c->G < 1 || c->S < 1 || kFc1K % (16 * c->S) != 0) return -3;
+    if (c->WPC < 1 || c->B % c->WPC != 0) return -4;
+    if (c->n_arena % 64 != 0) return -5;
+    return 0;
+}
+
+}  // namespace
+
+#define NF_LAUNCH_OK() (static_cast<int>(hipGetLastError()))
+
+extern "C" {
+
+int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
+
+// stage: 0 conv1_fwd, 1 conv2_fwd, 2 fc1_fwd, 3 head, 4 fc1_wgrad, 5 fc1_dgrad,
+//        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only
+int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
+    const int rc = check_ctx(c);
+    if (rc) return rc;
+    const dim3 img_grid(c->B, c->G);
+    switch (stage) {
+    case 0: hipLaunchKernelGGL(conv1_fwd_kernel, img_grid, dim3(256), 0, s, *c, idx_off); break;
+    case 1: hipLaunchKernelGGL(conv2_fwd_kernel, img_grid, dim3(256), kFwdLds, s, *c); break;
+    case 2: hipLaunchKernelGGL(fc1_fwd_kernel, dim3(c->S, c->G), dim3(256), 0, s, *c); break;
+    case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / 16, c->G), dim3(256), 0, s, *c, idx_off, step); break;
+    case 4: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(72, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c); break;
+    case 5: hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(72, c->G), dim3(256), 128 * kTrPitch128, s, *c); break;
+    case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, img_grid, dim3(256), kDgLds, s, *c, idx_off); break;
+    case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
+    case 8: hipLaunchKernelGGL(finalize_kernel, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;
+    case 9: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0); break;
+    case 10: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 1); break;
+    default: return -10;
+    }
+    return NF_LAUNCH_OK();
+}
+
+// One full optimisation step for all G clients.
+int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
+    for (int stage = 0; stage <= 9; ++stage) {
+        const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// `steps` consecutive optimisation steps (one epoch) in one call.
+int nf_mnist_train_steps(const MnistCtx* c, int first_step, int steps, hipStream_t s) {
+    for (int i = 0; i < steps; ++i) {
+        const int rc = nf_mnist_train_step(c, (first_step + i) * c->B, first_step + i, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Forward + loss/accuracy only (ctx->train must be 0 and eval_out set).
+int nf_mnist_eval_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
+    if (c->train != 0 || c->eval_out == nullptr) return -11;
+    for (int stage = 0; stage <= 3; ++stage) {
+        const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int nf_mnist_pack(const MnistCtx* c, hipStream_t s) { return nf_mnist_stage(c, 10, 0, 0, s); }
+
+}  // extern "C"

@@ -126,7 +126,13 @@ class FederatedEngine:
         torch.manual_seed(cfg.seed)  # identical initial model on every rank
         self._model_factory = lambda: build_model(cfg.model, **cfg.model_kwargs)
         self._host_model = self._model_factory()
-        self.layout = ArenaLayout.from_module(self._host_model)
+        self.backend = self._resolve_backend()
+        if self.backend == "native":
+            from .mnist_native import make_layout
+
+            self.layout = make_layout(self._host_model)
+        else:
+            self.layout = ArenaLayout.from_module(self._host_model)
         self.global_arena = ParameterArena(self.layout, self.device)
         self.global_arena.load_state_dict(self._host_model.state_dict())
         self.comm.broadcast(self.global_arena.data, src=0)
@@ -156,14 +162,7 @@ class FederatedEngine:
         cfg = self.cfg
         if factory is not None:
             return factory(cfg, self.pool, self.shards, self._model_factory, self.data)
-        backend = cfg.backend
-        if backend == "auto":
-            backend = (
-                "native"
-                if cfg.model == "mnist_cnn" and self.device.type == "cuda" and cfg.dp is None
-                else "torch"
-            )
-        if backend == "native":
+        if self.backend == "native":
             from .mnist_native import MnistCnnNativeTrainer
 
             return MnistCnnNativeTrainer(cfg, self.pool, self.shards, self.data)
@@ -171,6 +170,16 @@ class FederatedEngine:
             cfg, self.pool, self.shards, self._model_factory,
             self.data.eval_inputs, self.data.eval_labels,
         )
+
+    def _resolve_backend(self) -> str:
+        cfg = self.cfg
+        if cfg.backend != "auto":
+            return cfg.backend
+        native_ok = (
+            cfg.model == "mnist_cnn" and self.device.type == "cuda"
+            and cfg.dp is None and cfg.batch_size == 64
+        )
+        return "native" if native_ok else "torch"
 
     def _setup_persistence(self) -> None:
         from nanofed_amd.server.model_manager import ModelManager

@@ -1,0 +1,357 @@
+"""Native (hand-written HIP) local trainer for the MNIST CNN.
+
+Implements the ``GroupTrainer`` interface on top of csrc/hip/mnist_cnn.hip:
+all G simulated clients of a GPU advance one SGD step per group of ten kernel
+launches, and one local epoch (all steps of all clients) is recorded once in a
+hipGraph and replayed - the index table, the valid-sample table and the
+dropout step counter live in device memory, so a replay trains on the next
+epoch's shuffled batches without any host involvement.
+
+Training semantics are the reference's (nanofed/trainer/base.py:134-198 with
+nanofed/models/mnist.py:16-28 and nanofed/trainer/torch.py:14): per batch
+forward, mean cross-entropy, backward, plain SGD; the partial last batch of a
+shard is kept (``drop_last=False``) by giving its padding rows zero loss
+weight.  Metrics are the mean loss / accuracy over the batches of the last
+local epoch and the shard size.
+
+Parameter storage differs from PyTorch's for two tensors (conv2.weight as
+[oc][kh][kw][c], fc1.weight with NHWC-flattened columns); ``make_layout``
+describes that with arena storage permutations, so ``state_dict`` /
+``load_state_dict`` of the arenas stay in PyTorch order.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
+
+import torch
+import torch.nn as nn
+
+from nanofed_amd.core.exceptions import DeviceError
+from nanofed_amd.ops import library
+from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
+
+from .config import EngineConfig
+from .data import DeviceShards, FederatedData
+from .trainers import (
+    M_ACC,
+    M_LOSS,
+    M_SAMPLES,
+    M_VALID,
+    METRIC_COLUMNS,
+    GroupTrainer,
+)
+
+BATCH = 64
+FC1_SPLITS = 36
+CONV2_WG_PER_CLIENT = 32
+
+STAGES = {
+    "conv1_fwd": 0, "conv2_fwd": 1, "fc1_fwd": 2, "head": 3, "fc1_wgrad": 4,
+    "fc1_dgrad": 5, "conv2_dgrad": 6, "conv2_wgrad": 7, "finalize": 8,
+    "sgd_pack": 9, "pack": 10,
+}
+
+
+class MnistCtx(ctypes.Structure):
+    """Mirror of ``struct MnistCtx`` in csrc/hip/mnist_cnn.hip."""
+
+    _fields_ = [
+        ("G", c_int), ("B", c_int), ("S", c_int), ("WPC", c_int),
+        ("train", c_int), ("client_base", c_int), ("pad0", c_int), ("pad1", c_int),
+        ("images", c_void_p), ("labels", c_void_p),
+        ("idx", c_void_p), ("idx_stride", c_long),
+        ("nvalid", c_void_p), ("nvalid_stride", c_long),
+        ("arena", c_void_p), ("arena_stride", c_long),
+        ("grad", c_void_p), ("grad_stride", c_long),
+        ("shadow", c_void_p), ("shadow_stride", c_long),
+        ("w2t", c_void_p), ("w2t_stride", c_long),
+        ("n_arena", c_long),
+        ("off_c1w", c_int), ("off_c1b", c_int), ("off_c2w", c_int), ("off_c2b", c_int),
+        ("off_f1w", c_int), ("off_f1b", c_int), ("off_f2w", c_int), ("off_f2b", c_int),
+        ("a1", c_void_p), ("p2", c_void_p), ("pmask", c_void_p),
+        ("fc1_slabs", c_void_p), ("dh1", c_void_p), ("da2", c_void_p),
+        ("conv1_part", c_void_p), ("conv2_part", c_void_p), ("head_part", c_void_p),
+        ("metrics", c_void_p), ("eval_out", c_void_p),
+        ("step_counter", c_void_p), ("seed", c_ulonglong),
+        ("lr", c_float), ("wd", c_float), ("mean", c_float), ("inv_std", c_float),
+        ("p_drop1", c_float), ("p_drop2", c_float),
+    ]
+
+
+def _lib():
+    lib = library.hip_lib()
+    if not getattr(lib, "_mnist_declared", False):
+        P = ctypes.POINTER(MnistCtx)
+        lib.nf_mnist_ctx_size.restype = c_int
+        lib.nf_mnist_stage.argtypes = [P, c_int, c_int, c_int, c_void_p]
+        lib.nf_mnist_train_step.argtypes = [P, c_int, c_int, c_void_p]
+        lib.nf_mnist_train_steps.argtypes = [P, c_int, c_int, c_void_p]
+        lib.nf_mnist_eval_step.argtypes = [P, c_int, c_int, c_void_p]
+        lib.nf_mnist_pack.argtypes = [P, c_void_p]
+        for fn in ("nf_mnist_stage", "nf_mnist_train_step", "nf_mnist_train_steps",
+                   "nf_mnist_eval_step", "nf_mnist_pack"):
+            getattr(lib, fn).restype = c_int
+        if lib.nf_mnist_ctx_size() != ctypes.sizeof(MnistCtx):
+            raise DeviceError(
+                "MnistCtx layout mismatch between Python and the HIP library: "
+                f"{ctypes.sizeof(MnistCtx)} vs {lib.nf_mnist_ctx_size()}"
+            )
+        lib._mnist_declared = True
+    return lib
+
+
+def native_permutations() -> dict[str, torch.Tensor]:
+    """stored_flat = canonical_flat[perm] for the two re-ordered tensors."""
+    conv2 = torch.arange(64 * 32 * 9).view(64, 32, 3, 3).permute(0, 2, 3, 1).reshape(-1)
+    fc1 = torch.arange(128 * 9216).view(128, 64, 144).permute(0, 2, 1).reshape(-1)
+    return {"conv2.weight": conv2, "fc1.weight": fc1}
+
+
+def make_layout(module: nn.Module) -> ArenaLayout:
+    return ArenaLayout.from_module(module).with_perms(native_permutations())
+
+
+class NativeBuffers:
+    """Activations, gradients-in-flight and partial slabs for G concurrent
+    client batches, plus the ``MnistCtx`` that points at them."""
+
+    def __init__(
+        self,
+        layout: ArenaLayout,
+        G: int,
+        device: torch.device,
+        images: torch.Tensor,
+        labels: torch.Tensor,
+        arena: torch.Tensor,
+        arena_stride: int,
+        grad: torch.Tensor | None,
+        max_steps: int,
+        mean: float,
+        std: float,
+        cfg: EngineConfig | None = None,
+        client_base: int = 0,
+        train: bool = True,
+        seed: int = 0,
+    ) -> None:
+        if device.type != "cuda":
+            raise DeviceError("the native MNIST trainer needs a HIP device")
+        B = BATCH
+        self.G, self.device, self.max_steps = G, device, max(1, max_steps)
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=device)
+        self.images = images.reshape(images.shape[0], -1).contiguous()
+        if self.images.dtype != torch.uint8 or self.images.shape[1] != 784:
+            raise DeviceError("native MNIST trainer expects uint8 [N, 784] images")
+        self.labels = labels.to(device=device, dtype=torch.int32).contiguous()
+        self.idx = z(G, self.max_steps * B, dtype=torch.int32)
+        self.nvalid = z(G, self.max_steps, dtype=torch.int32)
+        self.shadow = z(G, layout.numel, dtype=torch.bfloat16)
+        self.w2t = z(G, 9 * 32 * 64, dtype=torch.bfloat16)
+        self.a1 = z(G, B, 676, 32, dtype=torch.bfloat16)
+        self.p2 = z(G, B, 144, 64, dtype=torch.bfloat16)
+        self.pmask = z(G, B, 144, 64, dtype=torch.uint8)
+        self.fc1_slabs = z(G, FC1_SPLITS, B, 128)
+        self.dh1 = z(G, B, 128, dtype=torch.bfloat16)
+        self.da2 = z(G, B, 576, 64, dtype=torch.bfloat16)
+        self.conv1_part = z(G, B, 320)
+        self.conv2_part = z(G, CONV2_WG_PER_CLIENT, 18496)
+        self.head_part = z(G, B // 16, 1440)
+        self.metrics = z(G, 4)
+        self.eval_out = z(2)
+        self.step_counter = z(1, dtype=torch.int64)
+        self.grad = grad if grad is not None else z(1, layout.trainable_numel)
+        self.arena = arena
+
+        c = MnistCtx()
+        c.G, c.B, c.S, c.WPC = G, B, FC1_SPLITS, CONV2_WG_PER_CLIENT
+        c.train = 1 if train else 0
+        c.client_base = client_base
+        c.images = self.images.data_ptr()
+        c.labels = self.labels.data_ptr()
+        c.idx, c.idx_stride = self.idx.data_ptr(), self.idx.shape[1]
+        c.nvalid, c.nvalid_stride = self.nvalid.data_ptr(), self.nvalid.shape[1]
+        c.arena, c.arena_stride = arena.data_ptr(), arena_stride
+        c.grad = self.grad.data_ptr()
+        c.grad_stride = layout.trainable_numel if grad is not None else 0
+        c.shadow = self.shadow.data_ptr()
+        c.shadow_stride = layout.numel if arena_stride else 0
+        c.w2t = self.w2t.data_ptr()
+        c.w2t_stride = self.w2t.shape[1] if arena_stride else 0
+        c.n_arena = layout.numel
+        for field, key in (
+            ("off_c1w", "conv1.weight"), ("off_c1b", "conv1.bias"),
+            ("off_c2w", "conv2.weight"), ("off_c2b", "conv2.bias"),
+            ("off_f1w", "fc1.weight"), ("off_f1b", "fc1.bias"),
+            ("off_f2w", "fc2.weight"), ("off_f2b", "fc2.bias"),
+        ):
+            setattr(c, field, layout[key].offset)
+        c.a1, c.p2, c.pmask = self.a1.data_ptr(), self.p2.data_ptr(), self.pmask.data_ptr()
+        c.fc1_slabs, c.dh1, c.da2 = (
+            self.fc1_slabs.data_ptr(), self.dh1.data_ptr(), self.da2.data_ptr())
+        c.conv1_part, c.conv2_part, c.head_part = (
+            self.conv1_part.data_ptr(), self.conv2_part.data_ptr(), self.head_part.data_ptr())
+        c.metrics = self.metrics.data_ptr()
+        c.eval_out = 0 if train else self.eval_out.data_ptr()
+        c.step_counter = self.step_counter.data_ptr()
+        c.seed = seed & (2**64 - 1)
+        c.lr = cfg.learning_rate if cfg else 0.0
+        c.wd = cfg.weight_decay if cfg else 0.0
+        c.mean, c.inv_std = mean, 1.0 / std
+        c.p_drop1, c.p_drop2 = 0.25, 0.5
+        self.ctx = c
+
+    def stream(self) -> c_void_p:
+        return library.stream_ptr(self.device)
+
+    def run_stage(self, name: str, idx_off: int = 0, step: int = 0) -> None:
+        library.check(
+            _lib().nf_mnist_stage(ctypes.byref(self.ctx), STAGES[name], idx_off, step,
+                                  self.stream()),
+            f"mnist stage {name}",
+        )
+
+    def pack(self) -> None:
+        library.check(_lib().nf_mnist_pack(ctypes.byref(self.ctx), self.stream()), "mnist pack")
+
+    def train_steps(self, first: int, count: int) -> None:
+        library.check(
+            _lib().nf_mnist_train_steps(ctypes.byref(self.ctx), first, count, self.stream()),
+            "mnist train steps",
+        )
+
+    def eval_step(self, idx_off: int, step: int) -> None:
+        library.check(
+            _lib().nf_mnist_eval_step(ctypes.byref(self.ctx), idx_off, step, self.stream()),
+            "mnist eval step",
+        )
+
+
+class MnistCnnNativeTrainer(GroupTrainer):
+    make_layout = staticmethod(make_layout)
+
+    def __init__(
+        self, cfg: EngineConfig, pool: ArenaPool, shards: DeviceShards, data: FederatedData
+    ) -> None:
+        if cfg.model != "mnist_cnn":
+            raise DeviceError("the native trainer implements the MNIST CNN only")
+        if cfg.batch_size != BATCH:
+            raise DeviceError(f"the native MNIST trainer is built for batch size {BATCH}")
+        if not pool.layout.perms:
+            raise DeviceError("the arena pool must use MnistCnnNativeTrainer.make_layout")
+        self.cfg, self.pool, self.shards = cfg, pool, shards
+        self.device = pool.data.device
+        G = len(pool)
+        self.max_steps = shards.max_steps()
+        mean, std = float(data.mean[0]), float(data.std[0])
+        self.buf = NativeBuffers(
+            pool.layout, G, self.device, shards.inputs, shards.labels, pool.data,
+            pool.layout.numel, pool.grad, self.max_steps, mean, std, cfg,
+            client_base=shards.client_ids[0] if shards.client_ids else 0,
+            train=True, seed=cfg.seed,
+        )
+        B = BATCH
+        nvalid = torch.zeros(G, self.max_steps, dtype=torch.int32)
+        for k in range(G):
+            n, steps = shards.sizes[k], shards.steps_per_epoch(k)
+            for s in range(steps):
+                nvalid[k, s] = min(B, n - s * B)
+        self.buf.nvalid.copy_(nvalid)
+        self.metrics = torch.zeros(G, METRIC_COLUMNS, dtype=torch.float32, device=self.device)
+        self._graph: torch.cuda.CUDAGraph | None = None
+        self._eval: NativeBuffers | None = None
+        self._eval_data = (data.eval_inputs, data.eval_labels, mean, std)
+        self._sizes = torch.tensor(
+            [float(s) for s in shards.sizes], dtype=torch.float32, device=self.device
+        )
+
+    # -- batches ----------------------------------------------------------
+    def _fill_indices(self, round_idx: int, epoch: int) -> None:
+        B = BATCH
+        for k in range(len(self.pool)):
+            perm = self.shards.epoch_permutation(k, round_idx, epoch).to(torch.int32)
+            row = self.buf.idx[k]
+            n = perm.numel()
+            row[:n] = perm
+            if n < row.numel():
+                row[n:] = perm[0]
+
+    def _ensure_graph(self, round_idx: int) -> None:
+        """Record one local epoch (every step of every client) in a hipGraph.
+        The eager warm-up that precedes the capture trains for real, so the
+        parameters and the dropout counter are restored afterwards."""
+        if not self.cfg.graph_capture or self._graph is not None:
+            return
+        saved = self.pool.data.clone()
+        counter = self.buf.step_counter.clone()
+        self.buf.pack()
+        self._fill_indices(round_idx, 0)
+        self.buf.train_steps(0, self.max_steps)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.buf.train_steps(0, self.max_steps)
+        self._graph = graph
+        self.pool.data.copy_(saved)
+        self.buf.step_counter.copy_(counter)
+
+    def _run_epoch(self) -> None:
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self.buf.train_steps(0, self.max_steps)
+
+    def train_round(self, round_idx: int) -> torch.Tensor:
+        cfg = self.cfg
+        self._ensure_graph(round_idx)
+        self.buf.pack()
+        for epoch in range(cfg.local_epochs):
+            self._fill_indices(round_idx, epoch)
+            self.buf.metrics.zero_()
+            self._run_epoch()
+        m = self.buf.metrics
+        batches = m[:, 2].clamp(min=1.0)
+        out = self.metrics
+        out.zero_()
+        out[:, M_SAMPLES] = self._sizes
+        out[:, M_LOSS] = m[:, 0] / batches
+        out[:, M_ACC] = m[:, 1] / batches
+        out[:, M_VALID] = 1.0
+        return out
+
+    # -- held-out evaluation ----------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, flat: torch.Tensor) -> dict[str, float]:
+        ex, ey, mean, std = self._eval_data
+        if ex is None or len(ex) == 0:
+            return {}
+        B = BATCH
+        n = len(ex)
+        nb = (n + B - 1) // B
+        GE = min(8, nb)
+        steps = (nb + GE - 1) // GE
+        if self._eval is None:
+            ev = NativeBuffers(
+                self.pool.layout, GE, self.device, ex.to(self.device), ey.to(self.device),
+                flat, 0, None, steps, mean, std, None, train=False,
+            )
+            idx = torch.zeros(GE, steps * B, dtype=torch.int32)
+            nvalid = torch.zeros(GE, steps, dtype=torch.int32)
+            for batch in range(nb):
+                g, s = batch % GE, batch // GE
+                lo, hi = batch * B, min(n, batch * B + B)
+                idx[g, s * B : s * B + (hi - lo)] = torch.arange(lo, hi, dtype=torch.int32)
+                nvalid[g, s] = hi - lo
+            ev.idx.copy_(idx)
+            ev.nvalid.copy_(nvalid)
+            self._eval = ev
+        ev = self._eval
+        if ev.arena.data_ptr() != flat.data_ptr():
+            ev.arena = flat
+            ev.ctx.arena = flat.data_ptr()
+        ev.eval_out.zero_()
+        ev.pack()
+        for s in range(steps):
+            ev.eval_step(s * B, s)
+        loss_sum, correct = ev.eval_out.tolist()
+        return {"loss": loss_sum / n, "accuracy": correct / n, "samples": float(n)}

@@ -52,8 +52,14 @@ class Segment:
 class ArenaLayout:
     """Immutable key -> segment table shared by every arena of one model."""
 
-    def __init__(self, segments: list[Segment]) -> None:
+    def __init__(
+        self, segments: list[Segment], perms: dict[str, torch.Tensor] | None = None
+    ) -> None:
         self.segments = tuple(segments)
+        # storage permutations: stored_flat = canonical_flat[perm] for the
+        # tensors a kernel family wants in its own element order
+        self.perms = dict(perms or {})
+        self.inv_perms = {k: torch.argsort(v) for k, v in self.perms.items()}
         self._by_name = {s.name: s for s in segments}
         if len(self._by_name) != len(segments):
             raise DeviceError("duplicate key in arena layout")
@@ -102,6 +108,13 @@ class ArenaLayout:
     def signature(self) -> tuple:
         return tuple((s.name, s.offset, s.shape) for s in self.segments)
 
+    def with_perms(self, perms: dict[str, torch.Tensor]) -> "ArenaLayout":
+        """Same table, with some tensors stored in a permuted element order."""
+        for name, perm in perms.items():
+            if perm.numel() != self[name].numel:
+                raise DeviceError(f"permutation of {name} has the wrong length")
+        return ArenaLayout(list(self.segments), perms)
+
 
 class ArenaStateDict(dict):
     """``state_dict``-shaped dictionary whose values are views into one flat
@@ -129,10 +142,14 @@ class ArenaStateDict(dict):
     def export(self, device: str | torch.device = "cpu") -> dict[str, torch.Tensor]:
         """Detached copy in the segments' original dtypes (checkpoint format)."""
         host = self.flat.detach().to(device)
-        return {
-            s.name: host[s.offset : s.offset + s.numel].view(s.shape).to(s.dtype).clone()
-            for s in self.layout.segments
-        }
+        out = {}
+        for s in self.layout.segments:
+            seg = host[s.offset : s.offset + s.numel]
+            inv = self.layout.inv_perms.get(s.name)
+            if inv is not None:
+                seg = seg[inv.to(seg.device)]
+            out[s.name] = seg.view(s.shape).to(s.dtype).clone()
+        return out
 
 
 class ParameterArena:
@@ -198,9 +215,11 @@ class ParameterArena:
         missing = [k for k in self.layout.keys() if k not in state]
         if missing:
             raise DeviceError(f"state is missing keys: {missing}")
-        if isinstance(state, ArenaStateDict) and state.layout is self.layout:
-            self.data.copy_(state.flat)
-            return
+        if isinstance(state, ArenaStateDict):
+            if state.layout is self.layout:
+                self.data.copy_(state.flat)
+                return
+            state = state.export(state.flat.device)  # canonical element order
         # stage on the host and move once: one H2D copy instead of one per key
         same_dev = all(
             isinstance(v, torch.Tensor) and v.device == self.device
@@ -215,9 +234,11 @@ class ParameterArena:
                 raise DeviceError(
                     f"{s.name}: expected {s.shape}, got {tuple(src.shape)}"
                 )
-            stage[s.offset : s.offset + s.numel].copy_(
-                src.detach().reshape(-1).to(torch.float32)
-            )
+            flat_src = src.detach().reshape(-1).to(torch.float32)
+            perm = self.layout.perms.get(s.name)
+            if perm is not None:
+                flat_src = flat_src[perm.to(flat_src.device)]
+            stage[s.offset : s.offset + s.numel].copy_(flat_src)
         if stage is not self.data:
             self.data.copy_(stage)
 
@@ -229,6 +250,11 @@ class ParameterArena:
         """Re-point ``module``'s parameters, gradients and float buffers at
         the arena, so autograd and the arena kernels operate on the same
         memory.  Integer buffers keep their own storage (``sync_buffers``)."""
+        if self.layout.perms:
+            raise DeviceError(
+                "an arena with permuted storage cannot back a torch module; "
+                "use state_dict()/load_state_dict() at the boundary"
+            )
         views = self.views()
         gviews = self.grad_views() if self.grad is not None else {}
         for name, p in module.named_parameters():
