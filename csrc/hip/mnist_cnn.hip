@@ -566,8 +566,8 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
         red[(wave * 32 + n) * 10 + 9] = cb;
     }
     __syncthreads();
-    if (tid < 320) {
-        const int ch = tid / 10, t = tid - ch * 10;
+    for (int i = tid; i < 320; i += 256) {
+        const int ch = i / 10, t = i - ch * 10;
         float s = 0.f;
         for (int w = 0; w < 4; ++w) s += red[(w * 32 + ch) * 10 + t];
         float* part = c.conv1_part + img * kConv1Part;
