@@ -20,15 +20,22 @@
 //                  fp32 partial slabs (deterministic reduction)
 //   head           slab reduce + bias + ReLU + dropout, fc2, log-softmax, NLL,
 //                  accuracy, d(logits), fc2 backward, d(h1)  - one launch
+//   fc1_dgrad      dp2 = dh1 W1 (W1 tile transposed by LDS tr-reads); dropout and
+//                  ReLU backward in the epilogue; writes the pooled gradient
+//                  (the 4x larger d(conv2 out) is never materialised: its two
+//                  consumers expand it from dp2 + the arg-max code while
+//                  filling LDS); also reduces conv2's bias gradient
 //   fc1_wgrad      dW1 = dh1^T p2, both operands transposed on the fly with
-//                  ds_read_b64_tr_b16
-//   fc1_dgrad      dp2 = dh1 W1 (W1 tile transposed by LDS tr-reads), fused with
-//                  dropout/max-pool/ReLU backward: scatters to d(conv2 out)
+//                  ds_read_b64_tr_b16; optionally applies the SGD update of
+//                  fc1.weight (98 % of the parameters) in its epilogue
 //   conv2_dgrad    implicit GEMM (K = 9 taps x 64), zero-halo LDS patch with XOR
-//                  swizzle; epilogue applies conv1's ReLU mask and reduces
-//                  conv1's weight/bias gradient, so d(a1) never reaches memory
+//                  swizzle; epilogue applies conv1's ReLU mask (bit words) and
+//                  feeds the masked accumulator tile straight back into MFMA as
+//                  the A operand of conv1's weight gradient (im2col of the
+//                  input as B), so d(a1) never reaches memory
 //   conv2_wgrad    pixels are the reduction dimension of both operands:
-//                  tr-reads for both; fp32 partial tiles per workgroup
+//                  tr-reads for both; register prefetch of the next band;
+//                  fp32 partial tiles per workgroup
 //   finalize       fixed-order sum of all partial slabs into the gradient arena,
 //                  loss/accuracy accumulation
 //   sgd_pack       SGD on the flat arena + bf16 shadow + transposed conv2 shadow
@@ -51,7 +58,8 @@ struct MnistCtx {
     int G, B, S, WPC;
     int train;            // 1: dropout active
     int client_base;      // global id of client 0 (dropout streams)
-    int pad0, pad1;
+    int fuse_sgd;         // 1: fc1_wgrad applies fc1.weight's SGD update itself
+    int pad1;
     const uint8_t* images;  // [N][784]
     const int32_t* labels;  // [N]
     const int32_t* idx;     // [G][idx_stride] dataset rows of every step
@@ -73,10 +81,12 @@ struct MnistCtx {
     uint8_t* pmask;         // [G][B][144][64] bits 0-1 argmax, bit 2 alive
     float* fc1_slabs;       // [G][S][B][128]
     bf16* dh1;              // [G][B][128]
-    bf16* da2;              // [G][B][576][64]
+    bf16* dp2;              // [G][B][144][64] gradient of the pooled activations
+    uint32_t* a1mask;       // [G][B][676] bit c = conv1 output (pixel, c) > 0
     float* conv1_part;      // [G][B][320]
-    float* conv2_part;      // [G][WPC][18496]
-    float* head_part;       // [G][B/16][1440]
+    float* conv2_part;      // [G][WPC][18432]
+    float* c2b_part;        // [G][72][64]
+    float* head_part;       // [G][B/8][1440]
     float* metrics;         // [G][4] loss sum, accuracy sum, batches, -
     float* eval_out;        // [2] loss sum, correct count (eval mode)
     unsigned long long* step_counter;
@@ -89,7 +99,8 @@ struct MnistCtx {
 namespace {
 
 constexpr int kA1Pix = 676, kA1C = 32, kP2Pix = 144, kC2 = 64, kFc1K = 9216;
-constexpr int kHeadPart = 1440, kConv2Part = 18496, kConv1Part = 320;
+constexpr int kHeadPart = 1440, kConv2Part = 18432, kConv1Part = 320, kHeadRows = 8;
+constexpr int kFc1Tiles = 72;
 
 __device__ __forceinline__ unsigned long long client_seed(const MnistCtx& c, int g) {
     return c.seed + 0x9E3779B97F4A7C15ull * static_cast<unsigned long long>(c.client_base + g + 1);
@@ -126,6 +137,7 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xs[(y + kh) * 28 + x + kw];
         bf16x8 o;
+        unsigned bits = 0;
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
             const int ch = cg * 8 + cc;
@@ -133,8 +145,14 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc = fmaf(ws[ch * 9 + t], xv[t], acc);
             o[cc] = f2bf(fmaxf(acc, 0.f));
+            bits |= (acc > 0.f ? 1u : 0u) << cc;
         }
         *reinterpret_cast<bf16x8*>(out + px * kA1C + cg * 8) = o;
+        // the four lanes of a pixel are adjacent: merge their 8-bit groups
+        unsigned m = bits << (8 * cg);
+        m |= __shfl_xor(m, 1, 64);
+        m |= __shfl_xor(m, 2, 64);
+        if (cg == 0) c.a1mask[(static_cast<long>(g) * c.B + b) * kA1Pix + px] = m;
     }
 }
 
@@ -168,11 +186,30 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
     const unsigned long long ctr = c.train ? *c.step_counter : 0ull;
     const unsigned long long seed = client_seed(c, g);
 
+    // band b+1 travels HBM -> registers while band b is being multiplied
+    uint4 pre[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int p = tid + i * 256;
+        if (p < 1040) pre[i] = reinterpret_cast<const uint4*>(a1img)[p];
+    }
     for (int band = 0; band < 3; ++band) {
         __syncthreads();
-        const uint4* src = reinterpret_cast<const uint4*>(a1img + band * 8 * 26 * kA1C);
-        for (int p = tid; p < 1040; p += 256)
-            *reinterpret_cast<uint4*>(smem + (p >> 2) * kFwdPitch + (p & 3) * 16) = src[p];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int p = tid + i * 256;
+            if (p < 1040)
+                *reinterpret_cast<uint4*>(smem + (p >> 2) * kFwdPitch + (p & 3) * 16) = pre[i];
+        }
+        if (band < 2) {
+            const uint4* src =
+                reinterpret_cast<const uint4*>(a1img + (band + 1) * 8 * 26 * kA1C);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int p = tid + i * 256;
+                if (p < 1040) pre[i] = src[p];
+            }
+        }
         __syncthreads();
 
 #pragma unroll 1
@@ -217,24 +254,33 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
     }
 }
 
+
 // ---------------------------------------------------------------------------
+template <int KC>
 __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
     const int kc = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int KC = kFc1K / c.S;
     const bf16* A0 = c.p2 + (static_cast<long>(g) * c.B + n) * kFc1K + kc * KC + 8 * h;
     const bf16* A1 = A0 + 32 * kFc1K;
     const bf16* Bp = c.shadow + g * c.shadow_stride + c.off_f1w +
                      static_cast<long>(wave * 32 + n) * kFc1K + kc * KC + 8 * h;
     f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll 8
-    for (int k = 0; k < KC; k += 16) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A0 + k);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A1 + k);
-        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Bp + k);
-        acc0 = mfma32(a0, bb, acc0);
-        acc1 = mfma32(a1, bb, acc1);
+    // 24 independent 16-byte loads in flight per lane, then 16 MFMAs
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 128) {
+        bf16x8 a0[8], a1[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a0[i] = *reinterpret_cast<const bf16x8*>(A0 + k0 + 16 * i);
+            a1[i] = *reinterpret_cast<const bf16x8*>(A1 + k0 + 16 * i);
+            bb[i] = *reinterpret_cast<const bf16x8*>(Bp + k0 + 16 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc0 = mfma32(a0[i], bb[i], acc0);
+            acc1 = mfma32(a1[i], bb[i], acc1);
+        }
     }
     float* out = c.fc1_slabs + ((static_cast<long>(g) * c.S + kc) * c.B) * 128 + wave * 32 + n;
 #pragma unroll
@@ -246,43 +292,50 @@ __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
 }
 
 // ---------------------------------------------------------------------------
+// 8 batch rows per workgroup; thread = (row r, 4 consecutive hidden units).
 __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int step) {
     const int hb = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    __shared__ float h1s[16][129];
-    __shared__ float dm[16][129];
-    __shared__ float w2[10][129];
-    __shared__ float lg[16][12];
-    __shared__ float dl[16][12];
-    __shared__ float red[2][16];
-    const int r0 = hb * 16;
+    __shared__ float h1s[kHeadRows][132];
+    __shared__ float dm[kHeadRows][132];
+    __shared__ float w2[10][132];
+    __shared__ float lg[kHeadRows][12];
+    __shared__ float dl[kHeadRows][12];
+    __shared__ float red[2][kHeadRows];
+    const int r0 = hb * kHeadRows;
     const float* wa = c.arena + g * c.arena_stride;
     for (int i = tid; i < 1280; i += 256) w2[i >> 7][i & 127] = wa[c.off_f2w + i];
 
     // A: reduce the split-K slabs, bias, ReLU, dropout
-    const int r = tid >> 4, j0 = (tid & 15) * 8;
+    const int r = tid >> 5, j0 = (tid & 31) * 4;
     const int b = r0 + r;
     {
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = wa[c.off_f1b + j0 + e];
-        for (int s = 0; s < c.S; ++s) {
-            const float4* p = reinterpret_cast<const float4*>(
-                c.fc1_slabs + ((static_cast<long>(g) * c.S + s) * c.B + b) * 128 + j0);
-            const float4 v0 = p[0], v1 = p[1];
-            acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
-            acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+        const float4 bv = *reinterpret_cast<const float4*>(wa + c.off_f1b + j0);
+        float4 s0 = bv, s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* base = c.fc1_slabs + (static_cast<long>(g) * c.S * c.B + b) * 128 + j0;
+        const long sstride = static_cast<long>(c.B) * 128;
+        int s = 0;
+#pragma unroll 6
+        for (; s + 1 < c.S; s += 2) {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + s * sstride);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (s + 1) * sstride);
+            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
         }
-        float u[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (s < c.S) {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + s * sstride);
+            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+        }
+        const float acc[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+        float u[4] = {1.f, 1.f, 1.f, 1.f};
         float sc = 1.0f;
         if (c.train) {
             const unsigned long long ctr = *c.step_counter;
             const unsigned long long blk = (static_cast<unsigned long long>(b) * 128 + j0) >> 2;
             nf::philox_samples(client_seed(c, g), 2 * ctr + 1, blk, 0, u);
-            nf::philox_samples(client_seed(c, g), 2 * ctr + 1, blk + 1, 0, u + 4);
             sc = 1.0f / (1.0f - c.p_drop2);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 4; ++e) {
             bool alive = acc[e] > 0.f;
             if (c.train) alive = alive && (u[e] >= c.p_drop2);
             h1s[r][j0 + e] = alive ? acc[e] * sc : 0.f;
@@ -292,7 +345,7 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
     __syncthreads();
 
     // B: logits
-    if (tid < 160) {
+    if (tid < kHeadRows * 10) {
         const int rr = tid / 10, o = tid - rr * 10;
         float acc = wa[c.off_f2b + o];
 #pragma unroll 8
@@ -303,7 +356,7 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
 
     // C: log-softmax, NLL, accuracy, d(logits)
     const int nv = c.nvalid[g * c.nvalid_stride + step];
-    if (tid < 16) {
+    if (tid < kHeadRows) {
         const int bb = r0 + tid;
         const bool valid = bb < nv;
         const int y = c.labels[c.idx[g * c.idx_stride + idx_off + bb]];
@@ -326,7 +379,7 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
 
     float loss_sum = 0.f, correct = 0.f;
     if (tid == 0) {
-        for (int i = 0; i < 16; ++i) { loss_sum += red[0][i]; correct += red[1][i]; }
+        for (int i = 0; i < kHeadRows; ++i) { loss_sum += red[0][i]; correct += red[1][i]; }
     }
     if (!c.train && c.eval_out != nullptr) {
         if (tid == 0) {
@@ -336,38 +389,38 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         return;
     }
 
-    float* part = c.head_part + (static_cast<long>(g) * (c.B / 16) + hb) * kHeadPart;
-    // D: fc2 weight / bias gradient (partial over this block's 16 rows)
+    float* part = c.head_part + (static_cast<long>(g) * (c.B / kHeadRows) + hb) * kHeadPart;
+    // D: fc2 weight / bias gradient (partial over this block's rows)
     for (int i = tid; i < 1280; i += 256) {
         const int o = i >> 7, j = i & 127;
         float acc = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) acc = fmaf(dl[rr][o], h1s[rr][j], acc);
+        for (int rr = 0; rr < kHeadRows; ++rr) acc = fmaf(dl[rr][o], h1s[rr][j], acc);
         part[i] = acc;
     }
     if (tid < 10) {
         float acc = 0.f;
-        for (int rr = 0; rr < 16; ++rr) acc += dl[rr][tid];
+        for (int rr = 0; rr < kHeadRows; ++rr) acc += dl[rr][tid];
         part[1280 + tid] = acc;
     }
     // E: d(h1 pre-activation)
     {
-        bf16x8 o8;
+        bf16x4 o4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 4; ++e) {
             float v = 0.f;
 #pragma unroll
             for (int o = 0; o < 10; ++o) v = fmaf(dl[r][o], w2[o][j0 + e], v);
             v *= dm[r][j0 + e];
+            o4[e] = f2bf(v);
             dm[r][j0 + e] = v;
-            o8[e] = f2bf(v);
         }
-        *reinterpret_cast<bf16x8*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o8;
+        *reinterpret_cast<bf16x4*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o4;
     }
     __syncthreads();
     if (tid < 128) {
         float acc = 0.f;
-        for (int rr = 0; rr < 16; ++rr) acc += dm[rr][tid];
+        for (int rr = 0; rr < kHeadRows; ++rr) acc += dm[rr][tid];
         part[1296 + tid] = acc;
     }
     if (tid == 0) { part[1424] = loss_sum; part[1425] = correct; }
@@ -376,41 +429,6 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
 // ---------------------------------------------------------------------------
 constexpr int kTrPitch128 = 320;  // 256 B of data + 64 B: 4 consecutive k rows hit distinct banks
 
-__global__ void __launch_bounds__(256) fc1_wgrad_kernel(MnistCtx c) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_dh = smem;                    // [64 b][128 j]
-    char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
-    const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, n = lane & 31;
-    const bf16* dh = c.dh1 + static_cast<long>(g) * c.B * 128;
-    const bf16* p2 = c.p2 + static_cast<long>(g) * c.B * kFc1K + tile * 128;
-    for (int p = tid; p < 1024; p += 256) {
-        const int row = p >> 4, part = p & 15;
-        *reinterpret_cast<uint4*>(s_dh + row * kTrPitch128 + part * 16) =
-            *reinterpret_cast<const uint4*>(dh + row * 128 + part * 8);
-        *reinterpret_cast<uint4*>(s_p2 + row * kTrPitch128 + part * 16) =
-            *reinterpret_cast<const uint4*>(p2 + static_cast<long>(row) * kFc1K + part * 8);
-    }
-    __syncthreads();
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 Bfr = load_tr_frag(s_p2, kTrPitch128, ks * 16, wave * 32, lane);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const bf16x8 Afr = load_tr_frag(s_dh, kTrPitch128, ks * 16, mb * 32, lane);
-            acc[mb] = mfma32(Afr, Bfr, acc[mb]);
-        }
-    }
-    float* gr = c.grad + g * c.grad_stride + c.off_f1w + tile * 128 + wave * 32 + n;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            gr[static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K] = acc[mb][r];
-}
-
-// ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [128 j][128 k'] pitch 320
     const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
@@ -436,34 +454,113 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
         acc0 = mfma32(Af[0][ks], Bfr, acc0);
         acc1 = mfma32(Af[1][ks], Bfr, acc1);
     }
-    // dropout / max-pool / ReLU backward: route to the arg-max position
+    // dropout + ReLU backward on the pooled gradient; conv2 bias gradient
     const int pp = tile * 2 + (wave >> 1), ch = (wave & 1) * 32 + n;
-    const int ph = pp / 12, pw = pp - ph * 12;
     const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
-    const bf16 zero = f2bf(0.f);
+    float bsum = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int b = mb * 32 + acc_row(r, lane);
-            const long img = static_cast<long>(g) * c.B + b;
-            const uint8_t m = c.pmask[(img * kP2Pix + pp) * kC2 + ch];
-            const float v = (mb == 0 ? acc0[r] : acc1[r]) * ((m & 4) ? keep_scale : 0.f);
-            const bf16 vb = f2bf(v);
-            const int am = m & 3;
-            bf16* d = c.da2 + ((img * 576 + (2 * ph) * 24 + 2 * pw) * kC2 + ch);
-            d[0] = am == 0 ? vb : zero;
-            d[kC2] = am == 1 ? vb : zero;
-            d[24 * kC2] = am == 2 ? vb : zero;
-            d[25 * kC2] = am == 3 ? vb : zero;
+            const long o = ((static_cast<long>(g) * c.B + b) * kP2Pix + pp) * kC2 + ch;
+            const uint8_t m = c.pmask[o];
+            const bf16 vb = f2bf((mb == 0 ? acc0[r] : acc1[r]) * ((m & 4) ? keep_scale : 0.f));
+            c.dp2[o] = vb;
+            bsum += bf2f(vb);
         }
+    }
+    bsum += __shfl_xor(bsum, 32, 64);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (h == 0) red[wave * 32 + n] = bsum;
+    __syncthreads();
+    if (tid < 64) {
+        const int cb = tid >> 5, nn = tid & 31;
+        c.c2b_part[(static_cast<long>(g) * kFc1Tiles + tile) * 64 + tid] =
+            red[cb * 32 + nn] + red[(2 + cb) * 32 + nn];
     }
 }
 
 // ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fc1_wgrad_kernel(MnistCtx c, int step) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_dh = smem;                    // [64 b][128 j]
+    char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
+    const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31;
+    if (c.fuse_sgd && c.nvalid[g * c.nvalid_stride + step] == 0) return;
+    const bf16* dh = c.dh1 + static_cast<long>(g) * c.B * 128;
+    const bf16* p2 = c.p2 + static_cast<long>(g) * c.B * kFc1K + tile * 128;
+    for (int p = tid; p < 1024; p += 256) {
+        const int row = p >> 4, part = p & 15;
+        *reinterpret_cast<uint4*>(s_dh + row * kTrPitch128 + part * 16) =
+            *reinterpret_cast<const uint4*>(dh + row * 128 + part * 8);
+        *reinterpret_cast<uint4*>(s_p2 + row * kTrPitch128 + part * 16) =
+            *reinterpret_cast<const uint4*>(p2 + static_cast<long>(row) * kFc1K + part * 8);
+    }
+    const long col = static_cast<long>(tile) * 128 + wave * 32 + n;
+    float* pa = c.arena + g * c.arena_stride + c.off_f1w + col;
+    // start the read of the master weights early when the update is fused
+    __syncthreads();
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 Bfr = load_tr_frag(s_p2, kTrPitch128, ks * 16, wave * 32, lane);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const bf16x8 Afr = load_tr_frag(s_dh, kTrPitch128, ks * 16, mb * 32, lane);
+            acc[mb] = mfma32(Afr, Bfr, acc[mb]);
+        }
+    }
+    if (c.fuse_sgd) {
+        bf16* sh = c.shadow + g * c.shadow_stride + c.off_f1w + col;
+        const float lr = c.lr, wd = c.wd;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long o = static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K;
+                float pv = pa[o];
+                pv -= lr * fmaf(wd, pv, acc[mb][r]);
+                pa[o] = pv;
+                sh[o] = f2bf(pv);
+            }
+    } else {
+        float* gr = c.grad + g * c.grad_stride + c.off_f1w + col;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gr[static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K] = acc[mb][r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// d(conv2 out) at pixel (oy, ox), channels part*8..+7, from the pooled gradient
+// and the arg-max code: the value belongs to the window position that won.
+__device__ __forceinline__ uint4 expand_da2(const bf16* dp2img, const uint8_t* maskimg,
+                                            int oy, int ox, int part) {
+    const int pooled = (oy >> 1) * 12 + (ox >> 1);
+    const unsigned q = ((oy & 1) << 1) | (ox & 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
+    const uint2 m = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+    const unsigned mm[2] = {m.x, m.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned pair = mm[i >> 1] >> (16 * (i & 1));
+        const unsigned k0 = ((pair & 3u) == q) ? 0x0000FFFFu : 0u;
+        const unsigned k1 = (((pair >> 8) & 3u) == q) ? 0xFFFF0000u : 0u;
+        w[i] &= (k0 | k1);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 constexpr int kDgPatchRows = 13, kDgPatchCols = 28;
 constexpr int kDgPatchBytes = kDgPatchRows * kDgPatchCols * 128;  // 46592
-constexpr int kDgLds = kDgPatchBytes + 784 * 4 + 4 * 32 * 10 * 4;
+constexpr int kDgPixPad = 704;                                    // 22 blocks of 32
+constexpr int kDgLds = kDgPatchBytes + 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10 * 4;
 
 __device__ __forceinline__ int dg_swz(int pi, int part) {
     return pi * 128 + ((part ^ ((pi >> 1) & 7)) << 4);
@@ -471,8 +568,10 @@ __device__ __forceinline__ int dg_swz(int pi, int part) {
 
 __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);
-    float* red = xs + 784;
+    float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);       // normalised input image
+    int* soff = reinterpret_cast<int*>(xs + 784);                     // a1 pixel -> offset in xs
+    unsigned* smask = reinterpret_cast<unsigned*>(soff + kDgPixPad);  // a1 pixel -> ReLU bits
+    float* red = reinterpret_cast<float*>(smask + kDgPixPad);
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const long img = static_cast<long>(g) * c.B + b;
@@ -495,11 +594,20 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
             xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
             xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
         }
+        const uint32_t* am = c.a1mask + img * kA1Pix;
+        for (int p = tid; p < kDgPixPad; p += 256) {
+            const int y = p / 26, x = p - y * 26;
+            soff[p] = p < kA1Pix ? y * 28 + x : 0;
+            smask[p] = p < kA1Pix ? am[p] : 0u;
+        }
     }
-    float cw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float cb = 0.f;
-    const bf16* da2 = c.da2 + img * 576 * kC2;
-    const bf16* a1 = c.a1 + img * kA1Pix * kA1C;
+    // conv1 gradient tile Z[c][t]: t = 0..8 the taps, t = 9 the bias
+    f32x16 Z = {0};
+    const int tapoff = n < 9 ? (n / 3) * 28 + (n % 3) : 0;
+    const float xone = n == 9 ? 1.f : 0.f;
+    const bool xtap = n < 9;
+    const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
+    const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
 
     for (int chunk = 0; chunk < 3; ++chunk) {
         const int mb0 = chunk * 8;
@@ -516,7 +624,7 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
             const int oy = oy_base + pr, ox = pc - 2;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (oy >= 0 && oy < 24 && ox >= 0 && ox < 24)
-                v = *reinterpret_cast<const uint4*>(da2 + (oy * 24 + ox) * kC2 + part * 8);
+                v = expand_da2(dp2img, maskimg, oy, ox, part);
             *reinterpret_cast<uint4*>(smem + dg_swz(pi, part)) = v;
         }
         __syncthreads();
@@ -537,33 +645,30 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
                     smem + dg_swz(pi, (ks & 3) * 2 + h));
                 acc = mfma32(A, Bf[ks], acc);
             }
-            // ReLU mask of conv1's output, then conv1's weight gradient
+            // ReLU mask of conv1's output; the masked tile is the A operand
+            // (k = its own row index, in accumulator order) of
+            //   Z[c][t] += sum_pixels d(a1)[pixel][c] * x[pixel shifted by tap t]
+            const int pb = mb * 32 + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pp = mb * 32 + acc_row(r, lane);
-                if (pp < kA1Pix) {
-                    const float a = bf2f(a1[pp * kA1C + n]);
-                    const float d = a > 0.f ? acc[r] : 0.f;
-                    const int yy = pp / 26, xx = pp - yy * 26;
-                    cb += d;
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 Aa, Bx;
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                        for (int kw = 0; kw < 3; ++kw)
-                            cw[kh * 3 + kw] = fmaf(d, xs[(yy + kh) * 28 + xx + kw], cw[kh * 3 + kw]);
+                for (int j = 0; j < 8; ++j) {
+                    const int pp = pb + 16 * s + 8 * (j >> 2) + (j & 3);
+                    const unsigned bits = smask[pp];
+                    Aa[j] = f2bf(((bits >> n) & 1u) ? acc[8 * s + j] : 0.f);
+                    const float xv = xs[soff[pp] + tapoff];
+                    Bx[j] = f2bf(xtap ? xv : xone);
                 }
+                Z = mfma32(Aa, Bx, Z);
             }
         }
     }
-    // combine the two lane halves (same channel), then the four waves
-#pragma unroll
-    for (int t = 0; t < 9; ++t) cw[t] += __shfl_xor(cw[t], 32, 64);
-    cb += __shfl_xor(cb, 32, 64);
+    // Z: lane (t = n, half h) holds channels acc_row(r): combine the four waves
     __syncthreads();
-    if (h == 0) {
+    if (n < 10) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) red[(wave * 32 + n) * 10 + t] = cw[t];
-        red[(wave * 32 + n) * 10 + 9] = cb;
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + acc_row(r, lane)) * 10 + n] = Z[r];
     }
     __syncthreads();
     for (int i = tid; i < 320; i += 256) {
@@ -580,58 +685,74 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
 constexpr int kWgDaPitch = 192;  // 128 B of channels + 64 B
 constexpr int kWgDaBytes = 192 * kWgDaPitch;  // 36864
 constexpr int kWgA1Bytes = 260 * 64;          // 16640
-constexpr int kWgLds = kWgDaBytes + kWgA1Bytes + 6 * 64 * 4;
+constexpr int kWgLds = kWgDaBytes + kWgA1Bytes;
 
 __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_da = smem;               // [192 px][64 oc], pitch 192
     char* s_a1 = smem + kWgDaBytes;  // [260 px][32 c], pitch 64
-    float* red = reinterpret_cast<float*>(smem + kWgDaBytes + kWgA1Bytes);
     const int wg = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const int ocb = wave & 1, tg = wave >> 1;
     const int ipw = c.B / c.WPC;
+    const int nit = ipw * 3;
     f32x16 acc[3] = {{0}, {0}, {0}};
-    float bsum = 0.f;
     // per-lane pieces of the tap-shifted transposed read (see load_tr_frag)
     const int li = lane & 15;
     const int lq = li >> 2;
     const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
 
-    for (int im = wg * ipw; im < (wg + 1) * ipw; ++im) {
-        const long img = static_cast<long>(g) * c.B + im;
-        for (int band = 0; band < 3; ++band) {
-            __syncthreads();
-            const uint4* sda = reinterpret_cast<const uint4*>(c.da2 + (img * 576 + band * 192) * kC2);
-            for (int p = tid; p < 1536; p += 384)
-                *reinterpret_cast<uint4*>(s_da + (p >> 3) * kWgDaPitch + (p & 7) * 16) = sda[p];
-            const uint4* sa1 = reinterpret_cast<const uint4*>(
-                c.a1 + (img * kA1Pix + band * 8 * 26) * kA1C);
-            for (int p = tid; p < 1040; p += 384)
-                *reinterpret_cast<uint4*>(s_a1 + p * 16) = sa1[p];
-            __syncthreads();
-            {
-                const int oc = tid & 63, strip = tid >> 6;
-                for (int px = strip * 32; px < strip * 32 + 32; ++px)
-                    bsum += bf2f(*reinterpret_cast<const bf16*>(s_da + px * kWgDaPitch + oc * 2));
-            }
-#pragma unroll 2
-            for (int ks = 0; ks < 12; ++ks) {
-                const bf16x8 Afr = load_tr_frag(s_da, kWgDaPitch, ks * 16, ocb * 32, lane);
-                // the 8 pixels of this lane half: groups gi0, gi0 + 1 of 4 pixels
-                const int gi0 = 4 * ks + 2 * h;
-                const int oy0 = gi0 / 6, ox0 = 4 * (gi0 - oy0 * 6);
-                const int gi1 = gi0 + 1;
-                const int oy1 = gi1 / 6, ox1 = 4 * (gi1 - oy1 * 6);
+    // fixed piece -> (pixel, part) assignment of this thread
+    int dpx[4], dpart[4];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int tap = tg * 3 + t;  // kh = tg, kw = t
-                    const bf16x4 lo = lds_tr4(s_a1 + ((oy0 + tg) * 26 + ox0 + t + lq) * 64 + lcol);
-                    const bf16x4 hi = lds_tr4(s_a1 + ((oy1 + tg) * 26 + ox1 + t + lq) * 64 + lcol);
-                    (void)tap;
-                    const bf16x8 Bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[t] = mfma32(Afr, Bfr, acc[t]);
-                }
+    for (int i = 0; i < 4; ++i) { const int p = tid + i * 384; dpx[i] = p >> 3; dpart[i] = p & 7; }
+
+    uint4 pv[4], pa[3];
+    auto issue = [&](int it) {
+        const int im = wg * ipw + it / 3, band = it - (it / 3) * 3;
+        const long img = static_cast<long>(g) * c.B + im;
+        const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
+        const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = band * 8 + dpx[i] / 24, ox = dpx[i] % 24;
+            pv[i] = expand_da2(dp2img, maskimg, oy, ox, dpart[i]);
+        }
+        const uint4* sa1 = reinterpret_cast<const uint4*>(
+            c.a1 + (img * kA1Pix + band * 8 * 26) * kA1C);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int p = tid + i * 384;
+            if (p < 1040) pa[i] = sa1[p];
+        }
+    };
+    issue(0);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<uint4*>(s_da + dpx[i] * kWgDaPitch + dpart[i] * 16) = pv[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int p = tid + i * 384;
+            if (p < 1040) *reinterpret_cast<uint4*>(s_a1 + p * 16) = pa[i];
+        }
+        if (it + 1 < nit) issue(it + 1);
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 12; ++ks) {
+            const bf16x8 Afr = load_tr_frag(s_da, kWgDaPitch, ks * 16, ocb * 32, lane);
+            // the 8 pixels of this lane half: groups gi0, gi0 + 1 of 4 pixels
+            const int gi0 = 4 * ks + 2 * h;
+            const int oy0 = gi0 / 6, ox0 = 4 * (gi0 - oy0 * 6);
+            const int gi1 = gi0 + 1;
+            const int oy1 = gi1 / 6, ox1 = 4 * (gi1 - oy1 * 6);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {  // tap (kh, kw) = (tg, t)
+                const bf16x4 lo = lds_tr4(s_a1 + ((oy0 + tg) * 26 + ox0 + t + lq) * 64 + lcol);
+                const bf16x4 hi = lds_tr4(s_a1 + ((oy1 + tg) * 26 + ox1 + t + lq) * 64 + lcol);
+                const bf16x8 Bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[t] = mfma32(Afr, Bfr, acc[t]);
             }
         }
     }
@@ -645,18 +766,24 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
             part[(oc * 9 + tap) * 32 + n] = acc[t][r];
         }
     }
-    __syncthreads();
-    red[(tid >> 6) * 64 + (tid & 63)] = bsum;
-    __syncthreads();
-    if (tid < 64) {
-        float s = 0.f;
-        for (int st = 0; st < 6; ++st) s += red[st * 64 + tid];
-        part[18432 + tid] = s;
-    }
 }
 
 // ---------------------------------------------------------------------------
-constexpr int kSmallTotal = kConv1Part + kConv2Part + kHeadPart;
+constexpr int kSmallTotal = kConv1Part + kConv2Part + 64 + kHeadPart;
+
+__device__ __forceinline__ float sum_slabs(const float* p, int count, long stride) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+#pragma unroll 2
+    for (; i + 3 < count; i += 4) {
+        s0 += p[(i + 0) * stride];
+        s1 += p[(i + 1) * stride];
+        s2 += p[(i + 2) * stride];
+        s3 += p[(i + 3) * stride];
+    }
+    for (; i < count; ++i) s0 += p[i * stride];
+    return (s0 + s1) + (s2 + s3);
+}
 
 __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     const int g = blockIdx.y;
@@ -664,24 +791,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     if (e >= kSmallTotal) return;
     float* gr = c.grad + g * c.grad_stride;
     if (e < kConv1Part) {
-        const float* p = c.conv1_part + static_cast<long>(g) * c.B * kConv1Part + e;
-        float s = 0.f;
-        for (int b = 0; b < c.B; ++b) s += p[static_cast<long>(b) * kConv1Part];
+        const float s = sum_slabs(c.conv1_part + static_cast<long>(g) * c.B * kConv1Part + e,
+                                  c.B, kConv1Part);
         if (e < 288) gr[c.off_c1w + e] = s;
         else gr[c.off_c1b + e - 288] = s;
     } else if (e < kConv1Part + kConv2Part) {
         const int e2 = e - kConv1Part;
-        const float* p = c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2;
-        float s = 0.f;
-        for (int w = 0; w < c.WPC; ++w) s += p[static_cast<long>(w) * kConv2Part];
-        if (e2 < 18432) gr[c.off_c2w + e2] = s;
-        else gr[c.off_c2b + e2 - 18432] = s;
+        gr[c.off_c2w + e2] = sum_slabs(
+            c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2, c.WPC, kConv2Part);
+    } else if (e < kConv1Part + kConv2Part + 64) {
+        const int e2 = e - kConv1Part - kConv2Part;
+        gr[c.off_c2b + e2] = sum_slabs(
+            c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2, kFc1Tiles, 64);
     } else {
-        const int e3 = e - kConv1Part - kConv2Part;
-        const int hbn = c.B / 16;
-        const float* p = c.head_part + static_cast<long>(g) * hbn * kHeadPart + e3;
-        float s = 0.f;
-        for (int hb = 0; hb < hbn; ++hb) s += p[static_cast<long>(hb) * kHeadPart];
+        const int e3 = e - kConv1Part - kConv2Part - 64;
+        const int hbn = c.B / kHeadRows;
+        const float s = sum_slabs(c.head_part + static_cast<long>(g) * hbn * kHeadPart + e3,
+                                  hbn, kHeadPart);
         if (e3 < 1280) gr[c.off_f2w + e3] = s;
         else if (e3 < 1290) gr[c.off_f2b + e3 - 1280] = s;
         else if (e3 >= 1296 && e3 < 1424) gr[c.off_f1b + e3 - 1296] = s;
@@ -710,8 +836,16 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
     bf16* sh = c.shadow + g * c.shadow_stride;
     bf16* w2t = c.w2t + g * c.w2t_stride;
     const long n4 = c.n_arena >> 2;
+    const bool skip_fc1 = !force && c.fuse_sgd;  // fc1.weight was updated by fc1_wgrad
+    const long f1_lo = c.off_f1w >> 2, f1_hi = (c.off_f1w + 128L * kFc1K) >> 2;
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4;
          i += static_cast<long>(gridDim.x) * 256) {
+        if (skip_fc1 && i >= f1_lo && i < f1_hi) {
+            // jump over the segment in whole grid strides
+            const long stride = static_cast<long>(gridDim.x) * 256;
+            i += ((f1_hi - i + stride - 1) / stride - 1) * stride;
+            continue;
+        }
         float4 pv = reinterpret_cast<float4*>(p)[i];
         if (!force) {
             const float4 gv = reinterpret_cast<const float4*>(gr)[i];
@@ -736,7 +870,7 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
 
 inline int check_ctx(const MnistCtx* c) {
     if (c->B != 64) return -2;
-    if (c->G < 1 || c->S < 1 || kFc1K % (16 * c->S) != 0) return -3;
+    if (c->G < 1 || c->S != 36) return -3;
     if (c->WPC < 1 || c->B % c->WPC != 0) return -4;
     if (c->n_arena % 64 != 0) return -5;
     return 0;
@@ -750,7 +884,7 @@ extern "C" {
 
 int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
 
-// stage: 0 conv1_fwd, 1 conv2_fwd, 2 fc1_fwd, 3 head, 4 fc1_wgrad, 5 fc1_dgrad,
+// stage: 0 conv1_fwd, 1 conv2_fwd, 2 fc1_fwd, 3 head, 4 fc1_dgrad, 5 fc1_wgrad,
 //        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only
 int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
     const int rc = check_ctx(c);
@@ -759,10 +893,10 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     switch (stage) {
     case 0: hipLaunchKernelGGL(conv1_fwd_kernel, img_grid, dim3(256), 0, s, *c, idx_off); break;
     case 1: hipLaunchKernelGGL(conv2_fwd_kernel, img_grid, dim3(256), kFwdLds, s, *c); break;
-    case 2: hipLaunchKernelGGL(fc1_fwd_kernel, dim3(c->S, c->G), dim3(256), 0, s, *c); break;
-    case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / 16, c->G), dim3(256), 0, s, *c, idx_off, step); break;
-    case 4: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(72, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c); break;
-    case 5: hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(72, c->G), dim3(256), 128 * kTrPitch128, s, *c); break;
+    case 2: hipLaunchKernelGGL(fc1_fwd_kernel<256>, dim3(c->S, c->G), dim3(256), 0, s, *c); break;
+    case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / kHeadRows, c->G), dim3(256), 0, s, *c, idx_off, step); break;
+    case 4: hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 128 * kTrPitch128, s, *c); break;
+    case 5: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c, step); break;
     case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, img_grid, dim3(256), kDgLds, s, *c, idx_off); break;
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
     case 8: hipLaunchKernelGGL(finalize_kernel, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;

@@ -48,8 +48,8 @@ FC1_SPLITS = 36
 CONV2_WG_PER_CLIENT = 32
 
 STAGES = {
-    "conv1_fwd": 0, "conv2_fwd": 1, "fc1_fwd": 2, "head": 3, "fc1_wgrad": 4,
-    "fc1_dgrad": 5, "conv2_dgrad": 6, "conv2_wgrad": 7, "finalize": 8,
+    "conv1_fwd": 0, "conv2_fwd": 1, "fc1_fwd": 2, "head": 3, "fc1_dgrad": 4,
+    "fc1_wgrad": 5, "conv2_dgrad": 6, "conv2_wgrad": 7, "finalize": 8,
     "sgd_pack": 9, "pack": 10,
 }
 
@@ -59,7 +59,7 @@ class MnistCtx(ctypes.Structure):
 
     _fields_ = [
         ("G", c_int), ("B", c_int), ("S", c_int), ("WPC", c_int),
-        ("train", c_int), ("client_base", c_int), ("pad0", c_int), ("pad1", c_int),
+        ("train", c_int), ("client_base", c_int), ("fuse_sgd", c_int), ("pad1", c_int),
         ("images", c_void_p), ("labels", c_void_p),
         ("idx", c_void_p), ("idx_stride", c_long),
         ("nvalid", c_void_p), ("nvalid_stride", c_long),
@@ -71,8 +71,9 @@ class MnistCtx(ctypes.Structure):
         ("off_c1w", c_int), ("off_c1b", c_int), ("off_c2w", c_int), ("off_c2b", c_int),
         ("off_f1w", c_int), ("off_f1b", c_int), ("off_f2w", c_int), ("off_f2b", c_int),
         ("a1", c_void_p), ("p2", c_void_p), ("pmask", c_void_p),
-        ("fc1_slabs", c_void_p), ("dh1", c_void_p), ("da2", c_void_p),
-        ("conv1_part", c_void_p), ("conv2_part", c_void_p), ("head_part", c_void_p),
+        ("fc1_slabs", c_void_p), ("dh1", c_void_p), ("dp2", c_void_p), ("a1mask", c_void_p),
+        ("conv1_part", c_void_p), ("conv2_part", c_void_p), ("c2b_part", c_void_p),
+        ("head_part", c_void_p),
         ("metrics", c_void_p), ("eval_out", c_void_p),
         ("step_counter", c_void_p), ("seed", c_ulonglong),
         ("lr", c_float), ("wd", c_float), ("mean", c_float), ("inv_std", c_float),
@@ -134,6 +135,7 @@ class NativeBuffers:
         client_base: int = 0,
         train: bool = True,
         seed: int = 0,
+        fuse_sgd: bool = True,
     ) -> None:
         if device.type != "cuda":
             raise DeviceError("the native MNIST trainer needs a HIP device")
@@ -153,10 +155,12 @@ class NativeBuffers:
         self.pmask = z(G, B, 144, 64, dtype=torch.uint8)
         self.fc1_slabs = z(G, FC1_SPLITS, B, 128)
         self.dh1 = z(G, B, 128, dtype=torch.bfloat16)
-        self.da2 = z(G, B, 576, 64, dtype=torch.bfloat16)
+        self.dp2 = z(G, B, 144, 64, dtype=torch.bfloat16)
+        self.a1mask = z(G, B, 676, dtype=torch.int32)
         self.conv1_part = z(G, B, 320)
-        self.conv2_part = z(G, CONV2_WG_PER_CLIENT, 18496)
-        self.head_part = z(G, B // 16, 1440)
+        self.conv2_part = z(G, CONV2_WG_PER_CLIENT, 18432)
+        self.c2b_part = z(G, 72, 64)
+        self.head_part = z(G, B // 8, 1440)
         self.metrics = z(G, 4)
         self.eval_out = z(2)
         self.step_counter = z(1, dtype=torch.int64)
@@ -187,10 +191,15 @@ class NativeBuffers:
         ):
             setattr(c, field, layout[key].offset)
         c.a1, c.p2, c.pmask = self.a1.data_ptr(), self.p2.data_ptr(), self.pmask.data_ptr()
-        c.fc1_slabs, c.dh1, c.da2 = (
-            self.fc1_slabs.data_ptr(), self.dh1.data_ptr(), self.da2.data_ptr())
+        c.fc1_slabs, c.dh1, c.dp2 = (
+            self.fc1_slabs.data_ptr(), self.dh1.data_ptr(), self.dp2.data_ptr())
+        c.a1mask = self.a1mask.data_ptr()
         c.conv1_part, c.conv2_part, c.head_part = (
             self.conv1_part.data_ptr(), self.conv2_part.data_ptr(), self.head_part.data_ptr())
+        c.c2b_part = self.c2b_part.data_ptr()
+        # the SGD update of fc1.weight is applied by fc1_wgrad itself unless
+        # something has to look at the whole gradient first (DP clipping)
+        c.fuse_sgd = 1 if (train and fuse_sgd) else 0
         c.metrics = self.metrics.data_ptr()
         c.eval_out = 0 if train else self.eval_out.data_ptr()
         c.step_counter = self.step_counter.data_ptr()

@@ -1,0 +1,64 @@
+"""Per-kernel timing of the native MNIST-CNN step (hipEvent brackets around
+back-to-back launches of one stage).  Usage:
+    python tools/bench_mnist_stages.py [--clients 8] [--reps 200]
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from nanofed_amd.engine import EngineConfig, FederatedEngine  # noqa: E402
+from nanofed_amd.engine.mnist_native import STAGES  # noqa: E402
+from nanofed_amd.parallel import Communicator  # noqa: E402
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clients", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=200)
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    comm = Communicator(device=torch.device("cuda", 0))
+    cfg = EngineConfig(model="mnist_cnn", num_clients=args.clients, samples_per_client=640,
+                       batch_size=64, local_epochs=1, eval_samples=64, backend="native",
+                       graph_capture=False)
+    eng = FederatedEngine(cfg, comm=comm)
+    tr = eng.trainer
+    buf = tr.buf
+    tr._fill_indices(0, 0)
+    buf.pack()
+    buf.train_steps(0, 2)  # realistic activations / gradients in every buffer
+    torch.cuda.synchronize()
+    out = {}
+    order = [n for n in STAGES if n != "pack"]
+    for name in order:
+        for _ in range(10):
+            buf.run_stage(name, 0, 0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            buf.run_stage(name, 0, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) * 1000.0 / args.reps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps // 4):
+        buf.train_steps(0, 4)
+    e1.record()
+    torch.cuda.synchronize()
+    out["full_step"] = e0.elapsed_time(e1) * 1000.0 / (args.reps // 4 * 4)
+    out["sum_of_stages"] = sum(out[n] for n in order)
+    print(json.dumps({"clients": args.clients, "us": {k: round(v, 2) for k, v in out.items()}}))
+
+
+if __name__ == "__main__":
+    main()
