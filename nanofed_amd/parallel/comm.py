@@ -195,8 +195,10 @@ class Communicator:
             return local.unsqueeze(0).clone()
         staged = self._host_staged(local)
         src = local.detach().to("cpu") if staged else local.contiguous()
-        out = torch.empty((self.world_size, *src.shape), dtype=src.dtype, device=src.device)
-        dist.all_gather_into_tensor(out, src, group=self.group)
+        flat = src.reshape(-1)
+        out = torch.empty(self.world_size * flat.numel(), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, flat, group=self.group)
+        out = out.view(self.world_size, *src.shape)
         return out.to(local.device) if staged else out
 
     def max_over_ranks(self, value: float) -> float:

@@ -57,10 +57,10 @@ _STD_LEVEL = {
 class LogConfig:
     """Handler configuration for :meth:`Logger.configure`."""
 
-    level: LogLevel
-    color: bool
-    format: str
-    output: Literal["console", "file", "both"]
+    level: LogLevel = LogLevel.INFO
+    color: bool = True
+    format: str = _LINE_FORMAT
+    output: Literal["console", "file", "both"] = "console"
     log_dir: Path | None = None
 
 
