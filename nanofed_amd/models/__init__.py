@@ -15,4 +15,6 @@ def build_model(name: str, **kwargs):
     }
     if name not in table:
         raise ValueError(f"Unknown model '{name}'. Known: {sorted(table)}")
+    if name == "gpt2_125m":
+        return GPT2LM(GPT2Config(**kwargs)) if kwargs else GPT2LM()
     return table[name](**kwargs)
