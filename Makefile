@@ -1,0 +1,39 @@
+.PHONY: install build test test-gpu lint format clean bench docs changelog release-prepare release
+
+install:
+	python -m pip install -e . --no-build-isolation --no-deps
+
+build:
+	python -m nanofed_amd.native_build
+
+test: build
+	python -m pytest tests -q -m "not gpu"
+
+test-gpu: build
+	python -u -m pytest tests -q -m gpu --timeout 120 --timeout-method thread
+
+lint:
+	python -m compileall -q nanofed_amd tests bench.py
+	@command -v ruff >/dev/null && ruff check nanofed_amd tests || echo "ruff not installed: syntax check only"
+
+format:
+	@command -v ruff >/dev/null && ruff format nanofed_amd tests || echo "ruff not installed"
+
+bench: build
+	python bench.py
+
+clean:
+	rm -rf build nanofed_amd/_lib/*.so .pytest_cache gpurun_out
+	find . -name __pycache__ -type d -prune -exec rm -rf {} +
+
+docs:
+	@echo "documentation lives in docs/*.md, DESIGN.md and README.md"
+
+changelog:
+	python scripts/changelog.py
+
+release-prepare:
+	python scripts/prepare_release.py $(VERSION)
+
+release:
+	bash scripts/release.sh $(VERSION)
