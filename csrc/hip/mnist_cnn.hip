@@ -59,7 +59,7 @@ struct MnistCtx {
     int train;            // 1: dropout active
     int client_base;      // global id of client 0 (dropout streams)
     int fuse_sgd;         // 1: fc1_wgrad applies fc1.weight's SGD update itself
-    int pad1;
+    int dp_pass;          // 0: plain SGD; 1: norm pass of DP-SGD; 2: clipped pass
     const uint8_t* images;  // [N][784]
     const int32_t* labels;  // [N]
     const int32_t* idx;     // [G][idx_stride] dataset rows of every step
@@ -92,6 +92,9 @@ struct MnistCtx {
     unsigned long long* step_counter;
     unsigned long long seed;
     float lr, wd, mean, inv_std, p_drop1, p_drop2;
+    float dp_clip, dp_noise_std;  // per-sample L2 bound C, noise std on the SUM (sigma * C)
+    float* dp_normsq;       // [G][B][4] squared per-sample gradient norms: fc2, conv1, conv2.weight, -
+    float* dp_rowscale;     // [G][B] clip factor of every sample
 };
 
 }  // extern "C"
@@ -377,6 +380,20 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
     }
     __syncthreads();
 
+    if (c.dp_pass != 0 && tid < kHeadRows) {
+        const long bi = static_cast<long>(g) * c.B + r0 + tid;
+        if (c.dp_pass == 1) {
+            // per-sample gradient of fc2: dl (x) h1 and dl
+            float hsq = 1.f, dsq = 0.f;
+            for (int j = 0; j < 128; ++j) hsq = fmaf(h1s[tid][j], h1s[tid][j], hsq);
+            for (int o = 0; o < 10; ++o) dsq = fmaf(dl[tid][o], dl[tid][o], dsq);
+            c.dp_normsq[bi * 4 + 0] = hsq * dsq;
+        } else {
+            const float sc = c.dp_rowscale[bi];
+            for (int o = 0; o < 10; ++o) dl[tid][o] *= sc;
+        }
+    }
+    __syncthreads();
     float loss_sum = 0.f, correct = 0.f;
     if (tid == 0) {
         for (int i = 0; i < kHeadRows; ++i) { loss_sum += red[0][i]; correct += red[1][i]; }
@@ -671,6 +688,7 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
         for (int r = 0; r < 16; ++r) red[(wave * 32 + acc_row(r, lane)) * 10 + n] = Z[r];
     }
     __syncthreads();
+    float sq = 0.f;
     for (int i = tid; i < 320; i += 256) {
         const int ch = i / 10, t = i - ch * 10;
         float s = 0.f;
@@ -678,6 +696,14 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
         float* part = c.conv1_part + img * kConv1Part;
         if (t < 9) part[ch * 9 + t] = s;
         else part[288 + ch] = s;
+        sq = fmaf(s, s, sq);
+    }
+    if (c.dp_pass == 1) {  // this workgroup's tile IS one sample's conv1 gradient
+        sq = wave_sum(sq);
+        __syncthreads();
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) c.dp_normsq[img * 4 + 1] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -756,6 +782,24 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
             }
         }
     }
+    if (c.dp_pass == 1) {  // ipw == 1: the accumulators are one sample's conv2.weight gradient
+        float sq = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sq = fmaf(acc[t][r], acc[t][r], sq);
+        sq = wave_sum(sq);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < 6; ++w) tot += red[w];
+            c.dp_normsq[(static_cast<long>(g) * c.B + wg) * 4 + 2] = tot;
+        }
+        return;
+    }
     float* part = c.conv2_part + (static_cast<long>(g) * c.WPC + wg) * kConv2Part;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -765,6 +809,57 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
             const int oc = ocb * 32 + acc_row(r, lane);
             part[(oc * 9 + tap) * 32 + n] = acc[t][r];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// DP-SGD, between the norm pass and the clipped pass: one workgroup per sample
+// adds the analytic parts (fc1: ||dh1||^2 (||p2||^2 + 1); conv2.bias: per-channel
+// pixel sums of dp2) to the tile norms and writes the clip factor
+//   min(1, C / ||g_b||),  g_b = n * (gradient of the mean loss w.r.t. sample b).
+__global__ void __launch_bounds__(256) dp_scale_kernel(MnistCtx c, int step) {
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[3][4];
+    __shared__ float chs[4][64];
+    const long bi = static_cast<long>(g) * c.B + b;
+    float p2sq = 0.f;
+    const bf16* p2 = c.p2 + bi * kFc1K;
+    for (int i = tid; i < kFc1K / 8; i += 256) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p2 + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = bf2f(v[e]); p2sq = fmaf(f, f, p2sq); }
+    }
+    float dhsq = 0.f;
+    if (tid < 128) { const float f = bf2f(c.dh1[bi * 128 + tid]); dhsq = f * f; }
+    // conv2 bias: thread (strip = tid / 64, oc = tid % 64) sums 36 pooled pixels
+    {
+        const int oc = tid & 63, strip = tid >> 6;
+        const bf16* d = c.dp2 + bi * kP2Pix * kC2 + oc;
+        float sacc = 0.f;
+        for (int px = strip * 36; px < strip * 36 + 36; ++px) sacc += bf2f(d[px * kC2]);
+        chs[strip][oc] = sacc;
+    }
+    p2sq = wave_sum(p2sq);
+    dhsq = wave_sum(dhsq);
+    __syncthreads();
+    float cbsq = 0.f;
+    if (tid < 64) {
+        const float t = chs[0][tid] + chs[1][tid] + chs[2][tid] + chs[3][tid];
+        cbsq = t * t;
+    }
+    cbsq = wave_sum(cbsq);
+    if (lane == 0) { red[0][wave] = p2sq; red[1][wave] = dhsq; red[2][wave] = cbsq; }
+    __syncthreads();
+    if (tid == 0) {
+        const float P = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const float D = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float Cb = red[2][0];
+        const float* ns = c.dp_normsq + bi * 4;
+        const float total = ns[0] + ns[1] + ns[2] + D * (P + 1.f) + Cb;
+        const int nv = c.nvalid[g * c.nvalid_stride + step];
+        const float norm = static_cast<float>(nv) * sqrtf(fmaxf(total, 0.f));
+        c.dp_rowscale[bi] = fminf(1.f, c.dp_clip / (norm + 1e-6f));
     }
 }
 
@@ -827,7 +922,6 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
 // the step counter stays).
 __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int force) {
     const int g = blockIdx.y;
-    if (!force && g == 0 && blockIdx.x == 0 && threadIdx.x == 0) *c.step_counter += 1ull;
     float lr = c.lr, wd = c.wd;
     if (force) { lr = 0.f; wd = 0.f; }
     else if (c.nvalid[g * c.nvalid_stride + step] == 0) return;  // client has no batch left
@@ -837,6 +931,15 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
     bf16* w2t = c.w2t + g * c.w2t_stride;
     const long n4 = c.n_arena >> 2;
     const bool skip_fc1 = !force && c.fuse_sgd;  // fc1.weight was updated by fc1_wgrad
+    // DP-SGD: Gaussian noise of std sigma*C on the SUM of clipped gradients,
+    // i.e. sigma*C/n on the mean that the gradient arena holds
+    const bool noisy = !force && c.dp_pass == 2 && c.dp_noise_std > 0.f;
+    float nstd = 0.f;
+    unsigned long long nctr = 0ull;
+    if (noisy) {
+        nstd = c.dp_noise_std / static_cast<float>(c.nvalid[g * c.nvalid_stride + step]);
+        nctr = 2ull * (*c.step_counter) + 0x8000000000000000ull;
+    }
     const long f1_lo = c.off_f1w >> 2, f1_hi = (c.off_f1w + 128L * kFc1K) >> 2;
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4;
          i += static_cast<long>(gridDim.x) * 256) {
@@ -848,7 +951,13 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
         }
         float4 pv = reinterpret_cast<float4*>(p)[i];
         if (!force) {
-            const float4 gv = reinterpret_cast<const float4*>(gr)[i];
+            float4 gv = reinterpret_cast<const float4*>(gr)[i];
+            if (noisy) {
+                float z[4];
+                nf::philox_samples(client_seed(c, g), nctr, static_cast<unsigned long long>(i), 1, z);
+                gv.x = fmaf(nstd, z[0], gv.x); gv.y = fmaf(nstd, z[1], gv.y);
+                gv.z = fmaf(nstd, z[2], gv.z); gv.w = fmaf(nstd, z[3], gv.w);
+            }
             pv.x -= lr * fmaf(wd, pv.x, gv.x);
             pv.y -= lr * fmaf(wd, pv.y, gv.y);
             pv.z -= lr * fmaf(wd, pv.z, gv.z);
@@ -868,11 +977,18 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
     }
 }
 
+__global__ void bump_step_kernel(unsigned long long* counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1ull;
+}
+
 inline int check_ctx(const MnistCtx* c) {
     if (c->B != 64) return -2;
     if (c->G < 1 || c->S != 36) return -3;
     if (c->WPC < 1 || c->B % c->WPC != 0) return -4;
     if (c->n_arena % 64 != 0) return -5;
+    if (c->dp_pass != 0 &&
+        (c->WPC != c->B || c->fuse_sgd || c->dp_normsq == nullptr || c->dp_rowscale == nullptr))
+        return -6;
     return 0;
 }
 
@@ -900,19 +1016,40 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, img_grid, dim3(256), kDgLds, s, *c, idx_off); break;
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
     case 8: hipLaunchKernelGGL(finalize_kernel, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;
-    case 9: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0); break;
+    case 9:
+        hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0);
+        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, c->step_counter);
+        break;
+    case 11: hipLaunchKernelGGL(dp_scale_kernel, img_grid, dim3(256), 0, s, *c, step); break;
     case 10: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 1); break;
     default: return -10;
     }
     return NF_LAUNCH_OK();
 }
 
-// One full optimisation step for all G clients.
+// One full optimisation step for all G clients.  With DP-SGD enabled
+// (ctx->dp_pass != 0) the backward runs twice: a norm pass that measures every
+// sample's gradient norm (conv tiles are per image; fc layers analytically),
+// then - after dp_scale turned the norms into clip factors - a pass whose
+// d(logits) rows are scaled by those factors, which scales each sample's whole
+// gradient.  Noise is added by sgd_pack.
 int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
-    for (int stage = 0; stage <= 9; ++stage) {
-        const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
-        if (rc) return rc;
+    if (c->dp_pass == 0) {
+        for (int stage = 0; stage <= 9; ++stage) {
+            const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
+            if (rc) return rc;
+        }
+        return 0;
     }
+    MnistCtx p = *c;
+    static const int fwd[] = {0, 1, 2};
+    static const int norm_pass[] = {3, 4, 6, 7, 11};
+    static const int clip_pass[] = {3, 4, 5, 6, 7, 8, 9};
+    for (int st : fwd) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+    p.dp_pass = 1;
+    for (int st : norm_pass) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+    p.dp_pass = 2;
+    for (int st : clip_pass) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     return 0;
 }
 

@@ -177,7 +177,7 @@ class FederatedEngine:
             return cfg.backend
         native_ok = (
             cfg.model == "mnist_cnn" and self.device.type == "cuda"
-            and cfg.dp is None and cfg.batch_size == 64
+            and (cfg.dp is None or cfg.dp.mode == "per_sample") and cfg.batch_size == 64
         )
         return "native" if native_ok else "torch"
 

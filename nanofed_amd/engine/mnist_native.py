@@ -36,6 +36,7 @@ from .config import EngineConfig
 from .data import DeviceShards, FederatedData
 from .trainers import (
     M_ACC,
+    M_EPSILON,
     M_LOSS,
     M_SAMPLES,
     M_VALID,
@@ -50,7 +51,7 @@ CONV2_WG_PER_CLIENT = 32
 STAGES = {
     "conv1_fwd": 0, "conv2_fwd": 1, "fc1_fwd": 2, "head": 3, "fc1_dgrad": 4,
     "fc1_wgrad": 5, "conv2_dgrad": 6, "conv2_wgrad": 7, "finalize": 8,
-    "sgd_pack": 9, "pack": 10,
+    "sgd_pack": 9, "pack": 10, "dp_scale": 11,
 }
 
 
@@ -59,7 +60,7 @@ class MnistCtx(ctypes.Structure):
 
     _fields_ = [
         ("G", c_int), ("B", c_int), ("S", c_int), ("WPC", c_int),
-        ("train", c_int), ("client_base", c_int), ("fuse_sgd", c_int), ("pad1", c_int),
+        ("train", c_int), ("client_base", c_int), ("fuse_sgd", c_int), ("dp_pass", c_int),
         ("images", c_void_p), ("labels", c_void_p),
         ("idx", c_void_p), ("idx_stride", c_long),
         ("nvalid", c_void_p), ("nvalid_stride", c_long),
@@ -78,6 +79,8 @@ class MnistCtx(ctypes.Structure):
         ("step_counter", c_void_p), ("seed", c_ulonglong),
         ("lr", c_float), ("wd", c_float), ("mean", c_float), ("inv_std", c_float),
         ("p_drop1", c_float), ("p_drop2", c_float),
+        ("dp_clip", c_float), ("dp_noise_std", c_float),
+        ("dp_normsq", c_void_p), ("dp_rowscale", c_void_p),
     ]
 
 
@@ -136,6 +139,7 @@ class NativeBuffers:
         train: bool = True,
         seed: int = 0,
         fuse_sgd: bool = True,
+        dp=None,
     ) -> None:
         if device.type != "cuda":
             raise DeviceError("the native MNIST trainer needs a HIP device")
@@ -158,7 +162,11 @@ class NativeBuffers:
         self.dp2 = z(G, B, 144, 64, dtype=torch.bfloat16)
         self.a1mask = z(G, B, 676, dtype=torch.int32)
         self.conv1_part = z(G, B, 320)
-        self.conv2_part = z(G, CONV2_WG_PER_CLIENT, 18432)
+        # DP-SGD measures per-sample norms from per-image tiles: one image per workgroup
+        wpc = B if dp is not None else CONV2_WG_PER_CLIENT
+        self.conv2_part = z(G, wpc, 18432)
+        self.dp_normsq = z(G, B, 4)
+        self.dp_rowscale = z(G, B)
         self.c2b_part = z(G, 72, 64)
         self.head_part = z(G, B // 8, 1440)
         self.metrics = z(G, 4)
@@ -168,7 +176,7 @@ class NativeBuffers:
         self.arena = arena
 
         c = MnistCtx()
-        c.G, c.B, c.S, c.WPC = G, B, FC1_SPLITS, CONV2_WG_PER_CLIENT
+        c.G, c.B, c.S, c.WPC = G, B, FC1_SPLITS, wpc
         c.train = 1 if train else 0
         c.client_base = client_base
         c.images = self.images.data_ptr()
@@ -199,7 +207,12 @@ class NativeBuffers:
         c.c2b_part = self.c2b_part.data_ptr()
         # the SGD update of fc1.weight is applied by fc1_wgrad itself unless
         # something has to look at the whole gradient first (DP clipping)
-        c.fuse_sgd = 1 if (train and fuse_sgd) else 0
+        c.fuse_sgd = 1 if (train and fuse_sgd and dp is None) else 0
+        c.dp_normsq, c.dp_rowscale = self.dp_normsq.data_ptr(), self.dp_rowscale.data_ptr()
+        if dp is not None and train:
+            c.dp_pass = 2
+            c.dp_clip = dp.max_gradient_norm
+            c.dp_noise_std = dp.noise_multiplier * dp.max_gradient_norm
         c.metrics = self.metrics.data_ptr()
         c.eval_out = 0 if train else self.eval_out.data_ptr()
         c.step_counter = self.step_counter.data_ptr()
@@ -257,8 +270,23 @@ class MnistCnnNativeTrainer(GroupTrainer):
             pool.layout, G, self.device, shards.inputs, shards.labels, pool.data,
             pool.layout.numel, pool.grad, self.max_steps, mean, std, cfg,
             client_base=shards.client_ids[0] if shards.client_ids else 0,
-            train=True, seed=cfg.seed,
+            train=True, seed=cfg.seed, dp=cfg.dp,
         )
+        self._accountants = None
+        if cfg.dp is not None:
+            if cfg.dp.mode != "per_sample":
+                raise DeviceError("the native DP path clips per sample (DPConfig.mode='per_sample')")
+            from nanofed_amd.privacy import PrivacyConfig
+            from nanofed_amd.privacy.accountant.rdp import SubsampledRDPAccountant
+
+            pc = PrivacyConfig(
+                epsilon=min(max(cfg.dp.epsilon, 0.01), 10.0), delta=cfg.dp.delta,
+                max_gradient_norm=cfg.dp.max_gradient_norm,
+                noise_multiplier=cfg.dp.noise_multiplier,
+            )
+            self._accountants = [
+                SubsampledRDPAccountant(pc, dataset_size=max(n, 1)) for n in shards.sizes
+            ]
         B = BATCH
         nvalid = torch.zeros(G, self.max_steps, dtype=torch.int32)
         for k in range(G):
@@ -326,6 +354,14 @@ class MnistCnnNativeTrainer(GroupTrainer):
         out[:, M_LOSS] = m[:, 0] / batches
         out[:, M_ACC] = m[:, 1] / batches
         out[:, M_VALID] = 1.0
+        if self._accountants is not None:
+            # privacy spent is a pure function of the number of noisy steps
+            eps = []
+            for k, acc in enumerate(self._accountants):
+                for _ in range(cfg.local_epochs * self.shards.steps_per_epoch(k)):
+                    acc.add_noise_event(cfg.dp.noise_multiplier, BATCH)
+                eps.append(acc.get_privacy_spent().epsilon_spent)
+            out[:, M_EPSILON] = torch.tensor(eps, dtype=torch.float32).to(self.device)
         return out
 
     # -- held-out evaluation ----------------------------------------------
