@@ -38,24 +38,30 @@ def main() -> None:
     torch.cuda.synchronize()
     out = {}
     order = [n for n in STAGES if n != "pack"]
-    for name in order:
-        for _ in range(10):
-            buf.run_stage(name, 0, 0)
+    per_graph = 25
+
+    def timed_graph(fn, launches):
+        """hipGraph of `launches` back-to-back calls: no host launch gaps."""
+        fn()
         torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(launches):
+                fn()
+        graph.replay()
+        torch.cuda.synchronize()
+        reps = max(1, args.reps // launches)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(args.reps):
-            buf.run_stage(name, 0, 0)
+        for _ in range(reps):
+            graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) * 1000.0 / args.reps
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.reps // 4):
-        buf.train_steps(0, 4)
-    e1.record()
-    torch.cuda.synchronize()
-    out["full_step"] = e0.elapsed_time(e1) * 1000.0 / (args.reps // 4 * 4)
+        return e0.elapsed_time(e1) * 1000.0 / (reps * launches)
+
+    for name in order:
+        out[name] = timed_graph(lambda: buf.run_stage(name, 0, 0), per_graph)
+    out["full_step"] = timed_graph(lambda: buf.train_steps(0, 1), 8)
     out["sum_of_stages"] = sum(out[n] for n in order)
     print(json.dumps({"clients": args.clients, "us": {k: round(v, 2) for k, v in out.items()}}))
 
