@@ -60,6 +60,8 @@ struct MnistCtx {
     int client_base;      // global id of client 0 (dropout streams)
     int fuse_sgd;         // 1: fc1_wgrad applies fc1.weight's SGD update itself
     int dp_pass;          // 0: plain SGD; 1: norm pass of DP-SGD; 2: clipped pass
+    int split;            // conv2 fwd/dgrad workgroups per image: 1 (whole image) or 3 (one band)
+    int pad2;
     const uint8_t* images;  // [N][784]
     const int32_t* labels;  // [N]
     const int32_t* idx;     // [G][idx_stride] dataset rows of every step
@@ -83,13 +85,13 @@ struct MnistCtx {
     bf16* dh1;              // [G][B][128]
     bf16* dp2;              // [G][B][144][64] gradient of the pooled activations
     uint32_t* a1mask;       // [G][B][676] bit c = conv1 output (pixel, c) > 0
-    float* conv1_part;      // [G][B][320]
+    float* conv1_part;      // [G][B*split][320]
     float* conv2_part;      // [G][WPC][18432]
     float* c2b_part;        // [G][72][64]
     float* head_part;       // [G][B/8][1440]
     float* metrics;         // [G][4] loss sum, accuracy sum, batches, -
     float* eval_out;        // [2] loss sum, correct count (eval mode)
-    unsigned long long* step_counter;
+    unsigned long long* step_counter;  // [G] optimisation steps taken by each client
     unsigned long long seed;
     float lr, wd, mean, inv_std, p_drop1, p_drop2;
     float dp_clip, dp_noise_std;  // per-sample L2 bound C, noise std on the SUM (sigma * C)
@@ -131,8 +133,18 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
     __syncthreads();
 
     bf16* out = c.a1 + (static_cast<long>(g) * c.B + b) * (kA1Pix * kA1C);
+    // a thread always serves the same group of 8 channels (256 % 4 == 0):
+    // their 72 weights and 8 biases stay in registers
+    const int cg = tid & 3;
+    float wr[8][9], br[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        br[cc] = bs[cg * 8 + cc];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[cc][t] = ws[(cg * 8 + cc) * 9 + t];
+    }
     for (int task = tid; task < kA1Pix * 4; task += 256) {
-        const int px = task >> 2, cg = task & 3;
+        const int px = task >> 2;
         const int y = px / 26, x = px - y * 26;
         float xv[9];
 #pragma unroll
@@ -143,10 +155,9 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
         unsigned bits = 0;
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
-            const int ch = cg * 8 + cc;
-            float acc = bs[ch];
+            float acc = br[cc];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc = fmaf(ws[ch * 9 + t], xv[t], acc);
+            for (int t = 0; t < 9; ++t) acc = fmaf(wr[cc][t], xv[t], acc);
             o[cc] = f2bf(fmaxf(acc, 0.f));
             bits |= (acc > 0.f ? 1u : 0u) << cc;
         }
@@ -160,12 +171,21 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
 }
 
 // ---------------------------------------------------------------------------
-constexpr int kFwdPitch = 80;  // 64 B of channels + 16 B pad per pixel
-constexpr int kFwdLds = 260 * kFwdPitch;
+constexpr int kFwdLds = 260 * 64;
+
+// LDS image of a band: pixel p (= row * 26 + col) owns 64 bytes; its 16-byte
+// chunk ch is stored at chunk position ch ^ ((col >> 1) & 3).  With the
+// window-major row order of the MFMA blocks every ds_read_b128 lane group then
+// touches 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int fwd_swz(int pixel, int col, int chunk) {
+    return pixel * 64 + ((chunk ^ ((col >> 1) & 3)) << 4);
+}
 
 __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x / c.split, g = blockIdx.y, tid = threadIdx.x;
+    const int band0 = c.split == 1 ? 0 : blockIdx.x - b * c.split;
+    const int band1 = c.split == 1 ? 3 : band0 + 1;
     const int lane = tid & 63, wave = tid >> 6;
     const int nb = wave & 1, mgrp = wave >> 1;
     const int n = lane & 31, h = lane >> 5;
@@ -186,54 +206,61 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
     const bf16* a1img = c.a1 + (static_cast<long>(g) * c.B + b) * (kA1Pix * kA1C);
     const long out_img = (static_cast<long>(g) * c.B + b) * kP2Pix;
     const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
-    const unsigned long long ctr = c.train ? *c.step_counter : 0ull;
+    const unsigned long long ctr = c.train ? c.step_counter[g] : 0ull;
     const unsigned long long seed = client_seed(c, g);
+    // dropout decisions are 8-bit draws: p is honoured to 1/256
+    const unsigned drop_thr = static_cast<unsigned>(c.p_drop1 * 256.0f + 0.5f);
 
+    // fixed piece -> LDS address of this thread's share of a band (pieces
+    // tid + 256 i; only threads 0..15 own a fifth piece)
+    const int p4 = min(tid + 1024, 1039);
+    const bool has4 = tid + 1024 < 1040;
+#define NF_FWD_DST(p) fwd_swz((p) >> 2, ((p) >> 2) % 26, (p) & 3)
+    const int dst0 = NF_FWD_DST(tid), dst1 = NF_FWD_DST(tid + 256), dst2 = NF_FWD_DST(tid + 512),
+              dst3 = NF_FWD_DST(tid + 768), dst4 = NF_FWD_DST(p4);
+#undef NF_FWD_DST
     // band b+1 travels HBM -> registers while band b is being multiplied
-    uint4 pre[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int p = tid + i * 256;
-        if (p < 1040) pre[i] = reinterpret_cast<const uint4*>(a1img)[p];
+    // (named registers: an indexed array here ends up in scratch memory)
+    uint4 pre0, pre1, pre2, pre3, pre4;
+#define NF_FWD_ISSUE(band_)                                                               \
+    {                                                                                     \
+        const uint4* src_ = reinterpret_cast<const uint4*>(a1img + (band_) * 8 * 26 * kA1C); \
+        pre0 = src_[tid]; pre1 = src_[tid + 256]; pre2 = src_[tid + 512];                 \
+        pre3 = src_[tid + 768]; pre4 = src_[p4];                                          \
     }
-    for (int band = 0; band < 3; ++band) {
+    NF_FWD_ISSUE(band0)
+    for (int band = band0; band < band1; ++band) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int p = tid + i * 256;
-            if (p < 1040)
-                *reinterpret_cast<uint4*>(smem + (p >> 2) * kFwdPitch + (p & 3) * 16) = pre[i];
-        }
-        if (band < 2) {
-            const uint4* src =
-                reinterpret_cast<const uint4*>(a1img + (band + 1) * 8 * 26 * kA1C);
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int p = tid + i * 256;
-                if (p < 1040) pre[i] = src[p];
-            }
-        }
+        *reinterpret_cast<uint4*>(smem + dst0) = pre0;
+        *reinterpret_cast<uint4*>(smem + dst1) = pre1;
+        *reinterpret_cast<uint4*>(smem + dst2) = pre2;
+        *reinterpret_cast<uint4*>(smem + dst3) = pre3;
+        if (has4) *reinterpret_cast<uint4*>(smem + dst4) = pre4;
+        if (band + 1 < band1) NF_FWD_ISSUE(band + 1)
         __syncthreads();
+#undef NF_FWD_ISSUE
 
+        unsigned rnd[4] = {~0u, ~0u, ~0u, ~0u};
+        if (c.train) {
+            const unsigned long long blk =
+                ((static_cast<unsigned long long>(b) * 3 + band) * 2 + mgrp) * 64 + nb * 32 + n;
+            const nf::Philox4 r = nf::philox4x32_10(seed, 2 * ctr, blk);
+            rnd[0] = r.v[0]; rnd[1] = r.v[1]; rnd[2] = r.v[2]; rnd[3] = r.v[3];
+        }
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) {
             const int mbi = mgrp * 3 + i;
             const int by = mbi / 3, bx = mbi - by * 3;
             const int oy = by * 4 + dy, ox = bx * 8 + dx;
-            const char* abase = smem + (oy * 26 + ox) * kFwdPitch + h * 16;
+            const unsigned rbits = i == 0 ? rnd[0] : (i == 1 ? rnd[1] : rnd[2]);
             f32x16 acc = {0};
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
                 const int tap = s >> 1, kh = tap / 3, kw = tap - kh * 3;
+                const int col = ox + kw;
                 const bf16x8 A = *reinterpret_cast<const bf16x8*>(
-                    abase + (kh * 26 + kw) * kFwdPitch + (s & 1) * 32);
+                    smem + fwd_swz((oy + kh) * 26 + col, col, (s & 1) * 2 + h));
                 acc = mfma32(A, Bf[s], acc);
-            }
-            float u[4] = {1.f, 1.f, 1.f, 1.f};
-            if (c.train) {
-                const unsigned long long blk =
-                    ((static_cast<unsigned long long>(b) * 3 + band) * 6 + mbi) * 64 + nb * 32 + n;
-                nf::philox_samples(seed, 2 * ctr, blk, 0, u);
             }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
@@ -245,7 +272,7 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
                     if (v > best) { best = v; am = qq; }
                 }
                 bool alive = best > 0.f;
-                if (c.train) alive = alive && (u[rg] >= c.p_drop1);
+                if (c.train) alive = alive && (((rbits >> (8 * rg)) & 0xFFu) >= drop_thr);
                 const float val = alive ? best * keep_scale : 0.f;
                 const int ph = band * 4 + by * 2 + (rg >> 1);
                 const int pw = bx * 4 + 2 * (rg & 1) + h;
@@ -256,7 +283,6 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------
 template <int KC>
@@ -332,7 +358,7 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         float u[4] = {1.f, 1.f, 1.f, 1.f};
         float sc = 1.0f;
         if (c.train) {
-            const unsigned long long ctr = *c.step_counter;
+            const unsigned long long ctr = c.step_counter[g];
             const unsigned long long blk = (static_cast<unsigned long long>(b) * 128 + j0) >> 2;
             nf::philox_samples(client_seed(c, g), 2 * ctr + 1, blk, 0, u);
             sc = 1.0f / (1.0f - c.p_drop2);
@@ -579,8 +605,11 @@ constexpr int kDgPatchBytes = kDgPatchRows * kDgPatchCols * 128;  // 46592
 constexpr int kDgPixPad = 704;                                    // 22 blocks of 32
 constexpr int kDgLds = kDgPatchBytes + 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10 * 4;
 
-__device__ __forceinline__ int dg_swz(int pi, int part) {
-    return pi * 128 + ((part ^ ((pi >> 1) & 7)) << 4);
+// 128 bytes per patch pixel (row pr, column pc); chunk position is XOR-ed with
+// ((pc >> 1) + 5 * pr) & 7: conflict-free for 32 linear pixels of a 26-wide
+// image shifted by any tap, including the row wrap inside a block.
+__device__ __forceinline__ int dg_swz(int pr, int pc, int part) {
+    return (pr * kDgPatchCols + pc) * 128 + ((part ^ (((pc >> 1) + 5 * pr) & 7)) << 4);
 }
 
 __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_off) {
@@ -589,7 +618,9 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
     int* soff = reinterpret_cast<int*>(xs + 784);                     // a1 pixel -> offset in xs
     unsigned* smask = reinterpret_cast<unsigned*>(soff + kDgPixPad);  // a1 pixel -> ReLU bits
     float* red = reinterpret_cast<float*>(smask + kDgPixPad);
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x / c.split, g = blockIdx.y, tid = threadIdx.x;
+    const int chunk0 = c.split == 1 ? 0 : blockIdx.x - b * c.split;
+    const int chunk1 = c.split == 1 ? 3 : chunk0 + 1;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const long img = static_cast<long>(g) * c.B + b;
 
@@ -626,7 +657,7 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
     const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
     const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
 
-    for (int chunk = 0; chunk < 3; ++chunk) {
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         const int mb0 = chunk * 8;
         const int nmb = chunk < 2 ? 8 : 6;
         const int pix0 = mb0 * 32;
@@ -642,7 +673,7 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (oy >= 0 && oy < 24 && ox >= 0 && ox < 24)
                 v = expand_da2(dp2img, maskimg, oy, ox, part);
-            *reinterpret_cast<uint4*>(smem + dg_swz(pi, part)) = v;
+            *reinterpret_cast<uint4*>(smem + dg_swz(pr, pc, part)) = v;
         }
         __syncthreads();
 
@@ -652,14 +683,13 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
             if (mb >= mb0 + nmb) break;  // wave-uniform
             const int p = min(mb * 32 + n, kA1Pix - 1);
             const int y = p / 26, x = p - y * 26;
-            const int pi0 = (y - oy_base) * kDgPatchCols + x + 2;
+            const int pr0 = y - oy_base, pc0 = x + 2;
             f32x16 acc = {0};
 #pragma unroll
             for (int ks = 0; ks < 36; ++ks) {
                 const int tap = ks >> 2, kh = tap / 3, kw = tap - kh * 3;
-                const int pi = pi0 - kh * kDgPatchCols - kw;
                 const bf16x8 A = *reinterpret_cast<const bf16x8*>(
-                    smem + dg_swz(pi, (ks & 3) * 2 + h));
+                    smem + dg_swz(pr0 - kh, pc0 - kw, (ks & 3) * 2 + h));
                 acc = mfma32(A, Bf[ks], acc);
             }
             // ReLU mask of conv1's output; the masked tile is the A operand
@@ -693,7 +723,7 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
         const int ch = i / 10, t = i - ch * 10;
         float s = 0.f;
         for (int w = 0; w < 4; ++w) s += red[(w * 32 + ch) * 10 + t];
-        float* part = c.conv1_part + img * kConv1Part;
+        float* part = c.conv1_part + (img * c.split + chunk0) * kConv1Part;
         if (t < 9) part[ch * 9 + t] = s;
         else part[288 + ch] = s;
         sq = fmaf(s, s, sq);
@@ -720,51 +750,52 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
     const int wg = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const int ocb = wave & 1, tg = wave >> 1;
-    const int ipw = c.B / c.WPC;
-    const int nit = ipw * 3;
+    const int nit = 3 * c.B / c.WPC;  // image-bands per workgroup
+    const int it0 = wg * nit;
     f32x16 acc[3] = {{0}, {0}, {0}};
     // per-lane pieces of the tap-shifted transposed read (see load_tr_frag)
     const int li = lane & 15;
     const int lq = li >> 2;
     const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
 
-    // fixed piece -> (pixel, part) assignment of this thread
-    int dpx[4], dpart[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int p = tid + i * 384; dpx[i] = p >> 3; dpart[i] = p & 7; }
-
-    uint4 pv[4], pa[3];
-    auto issue = [&](int it) {
-        const int im = wg * ipw + it / 3, band = it - (it / 3) * 3;
-        const long img = static_cast<long>(g) * c.B + im;
-        const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
-        const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int oy = band * 8 + dpx[i] / 24, ox = dpx[i] % 24;
-            pv[i] = expand_da2(dp2img, maskimg, oy, ox, dpart[i]);
-        }
-        const uint4* sa1 = reinterpret_cast<const uint4*>(
-            c.a1 + (img * kA1Pix + band * 8 * 26) * kA1C);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int p = tid + i * 384;
-            if (p < 1040) pa[i] = sa1[p];
-        }
-    };
-    issue(0);
+    // fixed piece -> (pixel, part) assignment of this thread: pieces tid + 384 i.
+    // Named registers for the prefetched pieces (an indexed array lands in scratch).
+    const int q2 = min(tid + 768, 1039);
+    const bool has2 = tid + 768 < 1040;
+    uint4 pv0, pv1, pv2, pv3, pa0, pa1, pa2;
+#define NF_WG_DA(i_, dst_)                                                              \
+    {                                                                                   \
+        const int p_ = tid + (i_) * 384, px_ = p_ >> 3;                                 \
+        dst_ = expand_da2(dp2img_, maskimg_, band_ * 8 + px_ / 24, px_ % 24, p_ & 7);   \
+    }
+#define NF_WG_ISSUE(it_)                                                                \
+    {                                                                                   \
+        const int gi_ = it0 + (it_);                                                    \
+        const int im_ = gi_ / 3, band_ = gi_ - im_ * 3;                                 \
+        const long img_ = static_cast<long>(g) * c.B + im_;                             \
+        const bf16* dp2img_ = c.dp2 + img_ * kP2Pix * kC2;                              \
+        const uint8_t* maskimg_ = c.pmask + img_ * kP2Pix * kC2;                        \
+        NF_WG_DA(0, pv0) NF_WG_DA(1, pv1) NF_WG_DA(2, pv2) NF_WG_DA(3, pv3)             \
+        const uint4* sa1_ = reinterpret_cast<const uint4*>(                             \
+            c.a1 + (img_ * kA1Pix + band_ * 8 * 26) * kA1C);                            \
+        pa0 = sa1_[tid]; pa1 = sa1_[tid + 384]; pa2 = sa1_[q2];                         \
+    }
+#define NF_WG_DST(i_) (s_da + ((tid + (i_) * 384) >> 3) * kWgDaPitch + ((tid + (i_) * 384) & 7) * 16)
+    NF_WG_ISSUE(0)
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<uint4*>(s_da + dpx[i] * kWgDaPitch + dpart[i] * 16) = pv[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int p = tid + i * 384;
-            if (p < 1040) *reinterpret_cast<uint4*>(s_a1 + p * 16) = pa[i];
-        }
-        if (it + 1 < nit) issue(it + 1);
+        *reinterpret_cast<uint4*>(NF_WG_DST(0)) = pv0;
+        *reinterpret_cast<uint4*>(NF_WG_DST(1)) = pv1;
+        *reinterpret_cast<uint4*>(NF_WG_DST(2)) = pv2;
+        *reinterpret_cast<uint4*>(NF_WG_DST(3)) = pv3;
+        *reinterpret_cast<uint4*>(s_a1 + tid * 16) = pa0;
+        *reinterpret_cast<uint4*>(s_a1 + (tid + 384) * 16) = pa1;
+        if (has2) *reinterpret_cast<uint4*>(s_a1 + q2 * 16) = pa2;
+        if (it + 1 < nit) NF_WG_ISSUE(it + 1)
         __syncthreads();
+#undef NF_WG_DA
+#undef NF_WG_ISSUE
+#undef NF_WG_DST
 #pragma unroll 2
         for (int ks = 0; ks < 12; ++ks) {
             const bf16x8 Afr = load_tr_frag(s_da, kWgDaPitch, ks * 16, ocb * 32, lane);
@@ -886,8 +917,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     if (e >= kSmallTotal) return;
     float* gr = c.grad + g * c.grad_stride;
     if (e < kConv1Part) {
-        const float s = sum_slabs(c.conv1_part + static_cast<long>(g) * c.B * kConv1Part + e,
-                                  c.B, kConv1Part);
+        const int slabs = c.B * c.split;
+        const float s = sum_slabs(c.conv1_part + static_cast<long>(g) * slabs * kConv1Part + e,
+                                  slabs, kConv1Part);
         if (e < 288) gr[c.off_c1w + e] = s;
         else gr[c.off_c1b + e - 288] = s;
     } else if (e < kConv1Part + kConv2Part) {
@@ -938,7 +970,7 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
     unsigned long long nctr = 0ull;
     if (noisy) {
         nstd = c.dp_noise_std / static_cast<float>(c.nvalid[g * c.nvalid_stride + step]);
-        nctr = 2ull * (*c.step_counter) + 0x8000000000000000ull;
+        nctr = 2ull * c.step_counter[g] + 0x8000000000000000ull;
     }
     const long f1_lo = c.off_f1w >> 2, f1_hi = (c.off_f1w + 128L * kFc1K) >> 2;
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4;
@@ -977,17 +1009,22 @@ __global__ void __launch_bounds__(256) sgd_pack_kernel(MnistCtx c, int step, int
     }
 }
 
-__global__ void bump_step_kernel(unsigned long long* counter) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1ull;
+// A client's counter advances only when it really took a step, so its dropout
+// and noise streams do not depend on which other clients share the GPU.
+__global__ void bump_step_kernel(MnistCtx c, int step) {
+    const int g = threadIdx.x;
+    if (g < c.G && c.nvalid[g * c.nvalid_stride + step] > 0) c.step_counter[g] += 1ull;
 }
 
 inline int check_ctx(const MnistCtx* c) {
     if (c->B != 64) return -2;
-    if (c->G < 1 || c->S != 36) return -3;
-    if (c->WPC < 1 || c->B % c->WPC != 0) return -4;
+    if (c->G < 1 || c->G > 1024 || c->S != 36) return -3;
+    if (c->WPC < 1 || (3 * c->B) % c->WPC != 0) return -4;
+    if (c->split != 1 && c->split != 3) return -7;
     if (c->n_arena % 64 != 0) return -5;
     if (c->dp_pass != 0 &&
-        (c->WPC != c->B || c->fuse_sgd || c->dp_normsq == nullptr || c->dp_rowscale == nullptr))
+        (c->WPC != c->B || c->split != 1 || c->fuse_sgd || c->dp_normsq == nullptr ||
+         c->dp_rowscale == nullptr))
         return -6;
     return 0;
 }
@@ -1006,19 +1043,20 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     const int rc = check_ctx(c);
     if (rc) return rc;
     const dim3 img_grid(c->B, c->G);
+    const dim3 split_grid(c->B * c->split, c->G);
     switch (stage) {
     case 0: hipLaunchKernelGGL(conv1_fwd_kernel, img_grid, dim3(256), 0, s, *c, idx_off); break;
-    case 1: hipLaunchKernelGGL(conv2_fwd_kernel, img_grid, dim3(256), kFwdLds, s, *c); break;
+    case 1: hipLaunchKernelGGL(conv2_fwd_kernel, split_grid, dim3(256), kFwdLds, s, *c); break;
     case 2: hipLaunchKernelGGL(fc1_fwd_kernel<256>, dim3(c->S, c->G), dim3(256), 0, s, *c); break;
     case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / kHeadRows, c->G), dim3(256), 0, s, *c, idx_off, step); break;
     case 4: hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 128 * kTrPitch128, s, *c); break;
     case 5: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c, step); break;
-    case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, img_grid, dim3(256), kDgLds, s, *c, idx_off); break;
+    case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, split_grid, dim3(256), kDgLds, s, *c, idx_off); break;
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
     case 8: hipLaunchKernelGGL(finalize_kernel, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;
     case 9:
         hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0);
-        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, c->step_counter);
+        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1024), 0, s, *c, step);
         break;
     case 11: hipLaunchKernelGGL(dp_scale_kernel, img_grid, dim3(256), 0, s, *c, step); break;
     case 10: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 1); break;

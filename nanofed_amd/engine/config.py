@@ -53,6 +53,9 @@ class EngineConfig:
     graph_capture: bool = True
     reduce_algo: str = "auto"  # auto | allreduce | rs_ag
     drop_last: bool = False
+    # native MNIST kernels: conv2 workgroups per image (1 or 3); 0 = choose from
+    # the number of clients on the GPU
+    conv_split: int = 0
     # quorum / robustness (reference: CoordinatorConfig.min_completion_rate)
     min_clients: int = 1
     min_completion_rate: float = 1.0

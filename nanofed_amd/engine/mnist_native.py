@@ -61,6 +61,7 @@ class MnistCtx(ctypes.Structure):
     _fields_ = [
         ("G", c_int), ("B", c_int), ("S", c_int), ("WPC", c_int),
         ("train", c_int), ("client_base", c_int), ("fuse_sgd", c_int), ("dp_pass", c_int),
+        ("split", c_int), ("pad2", c_int),
         ("images", c_void_p), ("labels", c_void_p),
         ("idx", c_void_p), ("idx_stride", c_long),
         ("nvalid", c_void_p), ("nvalid_stride", c_long),
@@ -161,9 +162,15 @@ class NativeBuffers:
         self.dh1 = z(G, B, 128, dtype=torch.bfloat16)
         self.dp2 = z(G, B, 144, 64, dtype=torch.bfloat16)
         self.a1mask = z(G, B, 676, dtype=torch.int32)
-        self.conv1_part = z(G, B, 320)
+        self.conv1_part = z(G, 3 * B, 320)
         # DP-SGD measures per-sample norms from per-image tiles: one image per workgroup
-        wpc = B if dp is not None else CONV2_WG_PER_CLIENT
+        # few clients on the GPU: cut the conv2 kernels into one band per workgroup
+        # (3x the workgroups, 1/3 the work each) so the chip is not left idle
+        few = G <= 2 and dp is None
+        if cfg is not None and cfg.conv_split in (1, 3) and dp is None:
+            few = cfg.conv_split == 3
+        split = 3 if few else 1
+        wpc = B if dp is not None else (3 * B if few else CONV2_WG_PER_CLIENT)
         self.conv2_part = z(G, wpc, 18432)
         self.dp_normsq = z(G, B, 4)
         self.dp_rowscale = z(G, B)
@@ -171,12 +178,13 @@ class NativeBuffers:
         self.head_part = z(G, B // 8, 1440)
         self.metrics = z(G, 4)
         self.eval_out = z(2)
-        self.step_counter = z(1, dtype=torch.int64)
+        self.step_counter = z(G, dtype=torch.int64)
         self.grad = grad if grad is not None else z(1, layout.trainable_numel)
         self.arena = arena
 
         c = MnistCtx()
         c.G, c.B, c.S, c.WPC = G, B, FC1_SPLITS, wpc
+        c.split = split
         c.train = 1 if train else 0
         c.client_base = client_base
         c.images = self.images.data_ptr()
