@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
 }
 
 // ---------------------------------------------------------------------------
-constexpr int kFwdLds = 260 * 64;
+constexpr int kFwdLds = 64 * 592;  // filter staging (37888 B) > band image (260 * 64)
 
 // LDS image of a band: pixel p (= row * 26 + col) owns 64 bytes; its 16-byte
 // chunk ch is stored at chunk position ch ^ ((col >> 1) & 3).  With the
@@ -190,13 +190,24 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
     const int nb = wave & 1, mgrp = wave >> 1;
     const int n = lane & 31, h = lane >> 5;
 
-    // stationary operand: this wave's 32 output channels, all of K = 9 x 32
-    const bf16* w = c.shadow + g * c.shadow_stride + c.off_c2w +
-                    static_cast<long>(nb * 32 + n) * 288;
+    // stationary operand: this wave's 32 output channels, all of K = 9 x 32.
+    // The whole filter bank (36 KB, rows of 576 B padded to 592) goes through
+    // LDS once per workgroup: coalesced fetch, conflict-free fragment reads.
     bf16x8 Bf[18];
+    {
+        const uint4* wsrc =
+            reinterpret_cast<const uint4*>(c.shadow + g * c.shadow_stride + c.off_c2w);
 #pragma unroll
-    for (int s = 0; s < 18; ++s)
-        Bf[s] = *reinterpret_cast<const bf16x8*>(w + (s >> 1) * 32 + (s & 1) * 16 + 8 * h);
+        for (int i = 0; i < 9; ++i) {
+            const int p = tid + i * 256, row = p / 36, part = p - row * 36;
+            *reinterpret_cast<uint4*>(smem + row * 592 + part * 16) = wsrc[p];
+        }
+        __syncthreads();
+        const char* wrow = smem + (nb * 32 + n) * 592 + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) Bf[s] = *reinterpret_cast<const bf16x8*>(wrow + s * 32);
+        // the band loop starts with a barrier before this area is overwritten
+    }
     const float bias = (c.arena + g * c.arena_stride)[c.off_c2b + nb * 32 + n];
 
     // row m of a 32-pixel block is position q of pooling window wi (m = 4*wi + q)
@@ -285,31 +296,48 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-template <int KC>
+// Split-K slice of h1 = p2 W1^T: K chunk of 288 (18 MFMA steps) per workgroup.
+// Both operand tiles are fetched as whole 576-byte row segments (coalesced,
+// full cache lines) into LDS and read back as MFMA fragments; rows are padded
+// to 592 bytes so the 16 rows of a ds_read_b128 lane group fall on 16
+// different 16-byte slots.  (Fragment-shaped global loads - 64 lanes touching
+// 64 different cache lines per instruction - made this kernel address-bound.)
+constexpr int kFc1KC = 288, kFc1S = kFc1K / kFc1KC;      // 32 slabs
+constexpr int kFc1Pitch = kFc1KC * 2 + 16;                // 592
+constexpr int kFc1FwdLds = (128 + 64) * kFc1Pitch;        // 113664
+
 __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;                     // [128 j][288 k]
+    char* s_a = smem + 128 * kFc1Pitch;   // [64 b][288 k]
     const int kc = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const bf16* A0 = c.p2 + (static_cast<long>(g) * c.B + n) * kFc1K + kc * KC + 8 * h;
-    const bf16* A1 = A0 + 32 * kFc1K;
-    const bf16* Bp = c.shadow + g * c.shadow_stride + c.off_f1w +
-                     static_cast<long>(wave * 32 + n) * kFc1K + kc * KC + 8 * h;
+    const bf16* wsrc = c.shadow + g * c.shadow_stride + c.off_f1w + kc * kFc1KC;
+    const bf16* asrc = c.p2 + static_cast<long>(g) * c.B * kFc1K + kc * kFc1KC;
+    constexpr int kPiecesPerRow = kFc1KC / 8;  // 36
+#pragma unroll 6
+    for (int p = tid; p < 128 * kPiecesPerRow; p += 256) {
+        const int row = p / kPiecesPerRow, part = p - row * kPiecesPerRow;
+        *reinterpret_cast<uint4*>(s_w + row * kFc1Pitch + part * 16) =
+            *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * kFc1K + part * 8);
+    }
+#pragma unroll 3
+    for (int p = tid; p < 64 * kPiecesPerRow; p += 256) {
+        const int row = p / kPiecesPerRow, part = p - row * kPiecesPerRow;
+        *reinterpret_cast<uint4*>(s_a + row * kFc1Pitch + part * 16) =
+            *reinterpret_cast<const uint4*>(asrc + static_cast<long>(row) * kFc1K + part * 8);
+    }
+    __syncthreads();
+    const char* a0 = s_a + n * kFc1Pitch + 16 * h;
+    const char* a1 = a0 + 32 * kFc1Pitch;
+    const char* bp = s_w + (wave * 32 + n) * kFc1Pitch + 16 * h;
     f32x16 acc0 = {0}, acc1 = {0};
-    // 24 independent 16-byte loads in flight per lane, then 16 MFMAs
 #pragma unroll
-    for (int k0 = 0; k0 < KC; k0 += 128) {
-        bf16x8 a0[8], a1[8], bb[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            a0[i] = *reinterpret_cast<const bf16x8*>(A0 + k0 + 16 * i);
-            a1[i] = *reinterpret_cast<const bf16x8*>(A1 + k0 + 16 * i);
-            bb[i] = *reinterpret_cast<const bf16x8*>(Bp + k0 + 16 * i);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            acc0 = mfma32(a0[i], bb[i], acc0);
-            acc1 = mfma32(a1[i], bb[i], acc1);
-        }
+    for (int ks = 0; ks < kFc1KC / 16; ++ks) {
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
+        acc0 = mfma32(*reinterpret_cast<const bf16x8*>(a0 + ks * 32), bb, acc0);
+        acc1 = mfma32(*reinterpret_cast<const bf16x8*>(a1 + ks * 32), bb, acc1);
     }
     float* out = c.fc1_slabs + ((static_cast<long>(g) * c.S + kc) * c.B) * 128 + wave * 32 + n;
 #pragma unroll
@@ -489,6 +517,16 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             Af[mb][ks] = *reinterpret_cast<const bf16x8*>(dh + (mb * 32 + n) * 128 + ks * 16);
+    // the alive bits this lane will need in the epilogue: fetched now, used after the GEMM
+    const int pp = tile * 2 + (wave >> 1), ch = (wave & 1) * 32 + n;
+    uint8_t mk[2][16];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = mb * 32 + acc_row(r, lane);
+            mk[mb][r] = c.pmask[((static_cast<long>(g) * c.B + b) * kP2Pix + pp) * kC2 + ch];
+        }
     __syncthreads();
     f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
@@ -498,7 +536,6 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
         acc1 = mfma32(Af[1][ks], Bfr, acc1);
     }
     // dropout + ReLU backward on the pooled gradient; conv2 bias gradient
-    const int pp = tile * 2 + (wave >> 1), ch = (wave & 1) * 32 + n;
     const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
     float bsum = 0.f;
 #pragma unroll
@@ -507,7 +544,7 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
         for (int r = 0; r < 16; ++r) {
             const int b = mb * 32 + acc_row(r, lane);
             const long o = ((static_cast<long>(g) * c.B + b) * kP2Pix + pp) * kC2 + ch;
-            const uint8_t m = c.pmask[o];
+            const uint8_t m = mk[mb][r];
             const bf16 vb = f2bf((mb == 0 ? acc0[r] : acc1[r]) * ((m & 4) ? keep_scale : 0.f));
             c.dp2[o] = vb;
             bsum += bf2f(vb);
@@ -624,12 +661,26 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const long img = static_cast<long>(g) * c.B + b;
 
-    // stationary operand: W2 as [k = (tap, oc)][col = c]
-    const bf16* wt = c.w2t + g * c.w2t_stride + n * 64 + 8 * h;
+    // stationary operand: W2 as [k = (tap, oc)][col = c].  The 36 KB are fetched
+    // once per workgroup with coalesced loads into the (still unused) patch area
+    // and handed to the four waves from LDS; 128-byte rows, chunk XOR (row >> 1) & 7.
     bf16x8 Bf[36];
+    {
+        const uint4* wsrc = reinterpret_cast<const uint4*>(c.w2t + g * c.w2t_stride);
 #pragma unroll
-    for (int ks = 0; ks < 36; ++ks)
-        Bf[ks] = *reinterpret_cast<const bf16x8*>(wt + (ks >> 2) * (32 * 64) + (ks & 3) * 16);
+        for (int i = 0; i < 9; ++i) {
+            const int p = tid + i * 256, row = p >> 3, part = p & 7;
+            *reinterpret_cast<uint4*>(smem + row * 128 + ((part ^ ((row >> 1) & 7)) << 4)) = wsrc[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) {
+            const int row = (ks >> 2) * 32 + n, part = (ks & 3) * 2 + h;
+            Bf[ks] = *reinterpret_cast<const bf16x8*>(
+                smem + row * 128 + ((part ^ ((row >> 1) & 7)) << 4));
+        }
+        // the chunk loop starts with a barrier before the patch is overwritten
+    }
 
     {
         const int row = c.idx[g * c.idx_stride + idx_off + b];
@@ -666,14 +717,20 @@ __global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_of
         const int oy_base = ymin - 2;
         const int nrows = ymax - ymin + 3;
         __syncthreads();
-        for (int p = tid; p < nrows * kDgPatchCols * 8; p += 256) {
-            const int pi = p >> 3, part = p & 7;
+        // up to 12 pieces per thread; loads are unconditional (clamped
+        // coordinates) so that the unrolled iterations keep several in flight
+        const int npieces = nrows * kDgPatchCols * 8;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int p = tid + i * 256;
+            const int pcl = min(p, npieces - 1);
+            const int pi = pcl >> 3, part = pcl & 7;
             const int pr = pi / kDgPatchCols, pc = pi - pr * kDgPatchCols;
             const int oy = oy_base + pr, ox = pc - 2;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (oy >= 0 && oy < 24 && ox >= 0 && ox < 24)
-                v = expand_da2(dp2img, maskimg, oy, ox, part);
-            *reinterpret_cast<uint4*>(smem + dg_swz(pr, pc, part)) = v;
+            const bool inside = oy >= 0 && oy < 24 && ox >= 0 && ox < 24;
+            uint4 v = expand_da2(dp2img, maskimg, min(max(oy, 0), 23), min(max(ox, 0), 23), part);
+            if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
+            if (p < npieces) *reinterpret_cast<uint4*>(smem + dg_swz(pr, pc, part)) = v;
         }
         __syncthreads();
 
@@ -1018,7 +1075,7 @@ __global__ void bump_step_kernel(MnistCtx c, int step) {
 
 inline int check_ctx(const MnistCtx* c) {
     if (c->B != 64) return -2;
-    if (c->G < 1 || c->G > 1024 || c->S != 36) return -3;
+    if (c->G < 1 || c->G > 1024 || c->S != kFc1S) return -3;
     if (c->WPC < 1 || (3 * c->B) % c->WPC != 0) return -4;
     if (c->split != 1 && c->split != 3) return -7;
     if (c->n_arena % 64 != 0) return -5;
@@ -1047,7 +1104,14 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     switch (stage) {
     case 0: hipLaunchKernelGGL(conv1_fwd_kernel, img_grid, dim3(256), 0, s, *c, idx_off); break;
     case 1: hipLaunchKernelGGL(conv2_fwd_kernel, split_grid, dim3(256), kFwdLds, s, *c); break;
-    case 2: hipLaunchKernelGGL(fc1_fwd_kernel<256>, dim3(c->S, c->G), dim3(256), 0, s, *c); break;
+    case 2: {
+        static const hipError_t lds_ok = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(fc1_fwd_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, kFc1FwdLds);
+        if (lds_ok != hipSuccess) return -20;
+        hipLaunchKernelGGL(fc1_fwd_kernel, dim3(c->S, c->G), dim3(256), kFc1FwdLds, s, *c);
+        break;
+    }
     case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / kHeadRows, c->G), dim3(256), 0, s, *c, idx_off, step); break;
     case 4: hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 128 * kTrPitch128, s, *c); break;
     case 5: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c, step); break;

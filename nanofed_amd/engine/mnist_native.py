@@ -45,7 +45,7 @@ from .trainers import (
 )
 
 BATCH = 64
-FC1_SPLITS = 36
+FC1_SPLITS = 32
 CONV2_WG_PER_CLIENT = 32
 
 STAGES = {

@@ -23,6 +23,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--clients", type=int, default=8)
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--only", default="", help="comma-separated stage names")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     comm = Communicator(device=torch.device("cuda", 0))
@@ -38,6 +39,8 @@ def main() -> None:
     torch.cuda.synchronize()
     out = {}
     order = [n for n in STAGES if n != "pack"]
+    if args.only:
+        order = args.only.split(",")
     per_graph = 25
 
     def timed_graph(fn, launches):
@@ -61,7 +64,8 @@ def main() -> None:
 
     for name in order:
         out[name] = timed_graph(lambda: buf.run_stage(name, 0, 0), per_graph)
-    out["full_step"] = timed_graph(lambda: buf.train_steps(0, 1), 8)
+    if not args.only:
+        out["full_step"] = timed_graph(lambda: buf.train_steps(0, 1), 8)
     out["sum_of_stages"] = sum(out[n] for n in order)
     print(json.dumps({"clients": args.clients, "us": {k: round(v, 2) for k, v in out.items()}}))
 
