@@ -5,7 +5,7 @@
 //  step: nanofed/trainer/base.py:141-159) for the G simulated clients that share
 // one GPU, all of them in every launch (blockIdx.y = client).
 //
-// One optimisation step is ten launches, none of which synchronises with the
+// One optimisation step is nine launches, none of which synchronises with the
 // host; dropout offsets come from a device-side step counter, batch rows from
 // a device index table, so a whole epoch can be recorded in one hipGraph.
 //
@@ -37,8 +37,11 @@
 //                  tr-reads for both; register prefetch of the next band;
 //                  fp32 partial tiles per workgroup
 //   finalize       fixed-order sum of all partial slabs into the gradient arena,
-//                  loss/accuracy accumulation
+//                  loss/accuracy accumulation; when fc1_wgrad already applied
+//                  fc1.weight's update it also applies SGD to every other
+//                  parameter and ends the step
 //   sgd_pack       SGD on the flat arena + bf16 shadow + transposed conv2 shadow
+//                  (unfused and DP-SGD steps)
 //
 // Storage ("native") layout of the parameters: conv2.weight [oc][kh][kw][c],
 // fc1.weight [j][(ph*12+pw)*64 + c]; everything else as in PyTorch.
@@ -61,7 +64,7 @@ struct MnistCtx {
     int fuse_sgd;         // 1: fc1_wgrad applies fc1.weight's SGD update itself
     int dp_pass;          // 0: plain SGD; 1: norm pass of DP-SGD; 2: clipped pass
     int split;            // conv2 fwd/dgrad workgroups per image: 1 (whole image) or 3 (one band)
-    int pad2;
+    int conv1_split;      // conv1 workgroups per image: 1, 2 or 4
     const uint8_t* images;  // [N][784]
     const int32_t* labels;  // [N]
     const int32_t* idx;     // [G][idx_stride] dataset rows of every step
@@ -113,7 +116,8 @@ __device__ __forceinline__ unsigned long long client_seed(const MnistCtx& c, int
 
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off) {
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x / c.conv1_split, part = blockIdx.x % c.conv1_split;
+    const int g = blockIdx.y, tid = threadIdx.x;
     __shared__ float xs[784];
     __shared__ float ws[288];
     __shared__ float bs[32];
@@ -143,7 +147,8 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[cc][t] = ws[(cg * 8 + cc) * 9 + t];
     }
-    for (int task = tid; task < kA1Pix * 4; task += 256) {
+    const int kTasks = kA1Pix * 4 / c.conv1_split;  // a multiple of 4 for 1, 2, 4
+    for (int task = part * kTasks + tid; task < (part + 1) * kTasks; task += 256) {
         const int px = task >> 2;
         const int y = px / 26, x = px - y * 26;
         float xv[9];
@@ -968,41 +973,63 @@ __device__ __forceinline__ float sum_slabs(const float* p, int count, long strid
     return (s0 + s1) + (s2 + s3);
 }
 
+// kSgd: also apply the SGD update of the element (every parameter except
+// fc1.weight is covered by exactly one thread), refresh its bf16 copies and
+// advance the client's step counter - the whole tail of a step whose
+// fc1.weight update already happened in fc1_wgrad.
+template <bool kSgd>
 __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     const int g = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= kSmallTotal) return;
     float* gr = c.grad + g * c.grad_stride;
+    const int nv = c.nvalid[g * c.nvalid_stride + step];
+    int dst = -1;      // arena offset of the parameter this thread owns
+    int w2t_at = -1;   // conv2.weight only: position in the [tap][c][oc] copy
+    float s;
     if (e < kConv1Part) {
         const int slabs = c.B * c.split;
-        const float s = sum_slabs(c.conv1_part + static_cast<long>(g) * slabs * kConv1Part + e,
-                                  slabs, kConv1Part);
-        if (e < 288) gr[c.off_c1w + e] = s;
-        else gr[c.off_c1b + e - 288] = s;
+        s = sum_slabs(c.conv1_part + static_cast<long>(g) * slabs * kConv1Part + e, slabs,
+                      kConv1Part);
+        dst = e < 288 ? c.off_c1w + e : c.off_c1b + e - 288;
     } else if (e < kConv1Part + kConv2Part) {
         const int e2 = e - kConv1Part;
-        gr[c.off_c2w + e2] = sum_slabs(
-            c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2, c.WPC, kConv2Part);
+        s = sum_slabs(c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2, c.WPC,
+                      kConv2Part);
+        dst = c.off_c2w + e2;
+        const int oc = e2 / 288;
+        w2t_at = (e2 - oc * 288) * 64 + oc;
     } else if (e < kConv1Part + kConv2Part + 64) {
         const int e2 = e - kConv1Part - kConv2Part;
-        gr[c.off_c2b + e2] = sum_slabs(
-            c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2, kFc1Tiles, 64);
+        s = sum_slabs(c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2, kFc1Tiles, 64);
+        dst = c.off_c2b + e2;
     } else {
         const int e3 = e - kConv1Part - kConv2Part - 64;
         const int hbn = c.B / kHeadRows;
-        const float s = sum_slabs(c.head_part + static_cast<long>(g) * hbn * kHeadPart + e3,
-                                  hbn, kHeadPart);
-        if (e3 < 1280) gr[c.off_f2w + e3] = s;
-        else if (e3 < 1290) gr[c.off_f2b + e3 - 1280] = s;
-        else if (e3 >= 1296 && e3 < 1424) gr[c.off_f1b + e3 - 1296] = s;
+        s = sum_slabs(c.head_part + static_cast<long>(g) * hbn * kHeadPart + e3, hbn, kHeadPart);
+        if (e3 < 1280) dst = c.off_f2w + e3;
+        else if (e3 < 1290) dst = c.off_f2b + e3 - 1280;
+        else if (e3 >= 1296 && e3 < 1424) dst = c.off_f1b + e3 - 1296;
         else if (e3 == 1424 || e3 == 1425) {
-            const int nv = c.nvalid[g * c.nvalid_stride + step];
             if (nv > 0) {
                 float* m = c.metrics + g * 4;
                 if (e3 == 1424) { m[0] += s / nv; m[2] += 1.0f; }
                 else m[1] += s / nv;
             }
         }
+    }
+    if (dst >= 0) gr[dst] = s;
+    if (kSgd && nv > 0) {
+        if (dst >= 0) {
+            float* p = c.arena + g * c.arena_stride + dst;
+            const float v = *p - c.lr * fmaf(c.wd, *p, s);
+            *p = v;
+            const bf16 h = f2bf(v);
+            c.shadow[g * c.shadow_stride + dst] = h;
+            if (w2t_at >= 0) c.w2t[g * c.w2t_stride + w2t_at] = h;
+        }
+        // every reader of this step's counter ran in an earlier launch
+        if (e == 0) c.step_counter[g] += 1ull;
     }
 }
 
@@ -1078,6 +1105,7 @@ inline int check_ctx(const MnistCtx* c) {
     if (c->G < 1 || c->G > 1024 || c->S != kFc1S) return -3;
     if (c->WPC < 1 || (3 * c->B) % c->WPC != 0) return -4;
     if (c->split != 1 && c->split != 3) return -7;
+    if (c->conv1_split != 1 && c->conv1_split != 2 && c->conv1_split != 4) return -8;
     if (c->n_arena % 64 != 0) return -5;
     if (c->dp_pass != 0 &&
         (c->WPC != c->B || c->split != 1 || c->fuse_sgd || c->dp_normsq == nullptr ||
@@ -1095,14 +1123,15 @@ extern "C" {
 int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
 
 // stage: 0 conv1_fwd, 1 conv2_fwd, 2 fc1_fwd, 3 head, 4 fc1_dgrad, 5 fc1_wgrad,
-//        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only
+//        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only,
+//        11 dp_scale, 12 finalize + SGD of everything but fc1.weight (fuse_sgd only)
 int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
     const int rc = check_ctx(c);
     if (rc) return rc;
     const dim3 img_grid(c->B, c->G);
     const dim3 split_grid(c->B * c->split, c->G);
     switch (stage) {
-    case 0: hipLaunchKernelGGL(conv1_fwd_kernel, img_grid, dim3(256), 0, s, *c, idx_off); break;
+    case 0: hipLaunchKernelGGL(conv1_fwd_kernel, dim3(c->B * c->conv1_split, c->G), dim3(256), 0, s, *c, idx_off); break;
     case 1: hipLaunchKernelGGL(conv2_fwd_kernel, split_grid, dim3(256), kFwdLds, s, *c); break;
     case 2: {
         static const hipError_t lds_ok = hipFuncSetAttribute(
@@ -1117,7 +1146,11 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     case 5: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c, step); break;
     case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, split_grid, dim3(256), kDgLds, s, *c, idx_off); break;
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
-    case 8: hipLaunchKernelGGL(finalize_kernel, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;
+    case 8: hipLaunchKernelGGL(finalize_kernel<false>, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;
+    case 12:
+        if (!c->fuse_sgd || c->dp_pass != 0) return -12;
+        hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step);
+        break;
     case 9:
         hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0);
         hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1024), 0, s, *c, step);
@@ -1137,11 +1170,13 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
 // gradient.  Noise is added by sgd_pack.
 int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
     if (c->dp_pass == 0) {
-        for (int stage = 0; stage <= 9; ++stage) {
+        // with fc1.weight updated inside fc1_wgrad, one launch finishes the step
+        const int last = c->fuse_sgd ? 7 : 9;
+        for (int stage = 0; stage <= last; ++stage) {
             const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
             if (rc) return rc;
         }
-        return 0;
+        return c->fuse_sgd ? nf_mnist_stage(c, 12, idx_off, step, s) : 0;
     }
     MnistCtx p = *c;
     static const int fwd[] = {0, 1, 2};

@@ -51,7 +51,7 @@ CONV2_WG_PER_CLIENT = 32
 STAGES = {
     "conv1_fwd": 0, "conv2_fwd": 1, "fc1_fwd": 2, "head": 3, "fc1_dgrad": 4,
     "fc1_wgrad": 5, "conv2_dgrad": 6, "conv2_wgrad": 7, "finalize": 8,
-    "sgd_pack": 9, "pack": 10, "dp_scale": 11,
+    "sgd_pack": 9, "pack": 10, "dp_scale": 11, "finalize_sgd": 12,
 }
 
 
@@ -61,7 +61,7 @@ class MnistCtx(ctypes.Structure):
     _fields_ = [
         ("G", c_int), ("B", c_int), ("S", c_int), ("WPC", c_int),
         ("train", c_int), ("client_base", c_int), ("fuse_sgd", c_int), ("dp_pass", c_int),
-        ("split", c_int), ("pad2", c_int),
+        ("split", c_int), ("conv1_split", c_int),
         ("images", c_void_p), ("labels", c_void_p),
         ("idx", c_void_p), ("idx_stride", c_long),
         ("nvalid", c_void_p), ("nvalid_stride", c_long),
@@ -185,6 +185,7 @@ class NativeBuffers:
         c = MnistCtx()
         c.G, c.B, c.S, c.WPC = G, B, FC1_SPLITS, wpc
         c.split = split
+        c.conv1_split = 4 if G <= 2 else 1
         c.train = 1 if train else 0
         c.client_base = client_base
         c.images = self.images.data_ptr()

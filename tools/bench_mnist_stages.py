@@ -38,7 +38,7 @@ def main() -> None:
     buf.train_steps(0, 2)  # realistic activations / gradients in every buffer
     torch.cuda.synchronize()
     out = {}
-    order = [n for n in STAGES if n != "pack"]
+    order = [n for n in STAGES if n not in ("pack", "dp_scale")]
     if args.only:
         order = args.only.split(",")
     per_graph = 25
