@@ -365,6 +365,9 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
     __shared__ float red[2][kHeadRows];
     const int r0 = hb * kHeadRows;
     const float* wa = c.arena + g * c.arena_stride;
+    // the label is two dependent loads away: start them before anything else
+    int y = 0;
+    if (tid < kHeadRows) y = c.labels[c.idx[g * c.idx_stride + idx_off + r0 + tid]];
     for (int i = tid; i < 1280; i += 256) w2[i >> 7][i & 127] = wa[c.off_f2w + i];
 
     // A: reduce the split-K slabs, bias, ReLU, dropout
@@ -375,17 +378,13 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         float4 s0 = bv, s1 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* base = c.fc1_slabs + (static_cast<long>(g) * c.S * c.B + b) * 128 + j0;
         const long sstride = static_cast<long>(c.B) * 128;
-        int s = 0;
-#pragma unroll 6
-        for (; s + 1 < c.S; s += 2) {
+        // all slabs in flight at once (check_ctx pins S to kFc1S)
+#pragma unroll
+        for (int s = 0; s < kFc1S; s += 2) {
             const float4 v0 = *reinterpret_cast<const float4*>(base + s * sstride);
             const float4 v1 = *reinterpret_cast<const float4*>(base + (s + 1) * sstride);
             s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
             s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-        }
-        if (s < c.S) {
-            const float4 v0 = *reinterpret_cast<const float4*>(base + s * sstride);
-            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
         }
         const float acc[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
         float u[4] = {1.f, 1.f, 1.f, 1.f};
@@ -421,7 +420,6 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
     if (tid < kHeadRows) {
         const int bb = r0 + tid;
         const bool valid = bb < nv;
-        const int y = c.labels[c.idx[g * c.idx_stride + idx_off + bb]];
         float m = lg[tid][0];
         int pred = 0;
         for (int o = 1; o < 10; ++o)
@@ -959,70 +957,86 @@ __global__ void __launch_bounds__(256) dp_scale_kernel(MnistCtx c, int step) {
 // ---------------------------------------------------------------------------
 constexpr int kSmallTotal = kConv1Part + kConv2Part + 64 + kHeadPart;
 
-__device__ __forceinline__ float sum_slabs(const float* p, int count, long stride) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-#pragma unroll 2
-    for (; i + 3 < count; i += 4) {
+// Sum `count` slabs of one element: wave w of the block adds slabs
+// [w*count/4, (w+1)*count/4) in order, the four partial sums meet in LDS and are
+// added in a fixed order, so the result does not depend on timing.
+__device__ __forceinline__ float sum_slabs(const float* p, int count, long stride, int wave) {
+    const int lo = (count * wave) >> 2, hi = (count * (wave + 1)) >> 2;
+    float s0 = 0.f, s1 = 0.f;
+    int i = lo;
+#pragma unroll 4
+    for (; i + 1 < hi; i += 2) {
         s0 += p[(i + 0) * stride];
         s1 += p[(i + 1) * stride];
-        s2 += p[(i + 2) * stride];
-        s3 += p[(i + 3) * stride];
     }
-    for (; i < count; ++i) s0 += p[i * stride];
-    return (s0 + s1) + (s2 + s3);
+    if (i < hi) s0 += p[i * stride];
+    return s0 + s1;
 }
 
+// 64 elements per workgroup, the slabs of each split over the four waves.
 // kSgd: also apply the SGD update of the element (every parameter except
 // fc1.weight is covered by exactly one thread), refresh its bf16 copies and
 // advance the client's step counter - the whole tail of a step whose
 // fc1.weight update already happened in fc1_wgrad.
 template <bool kSgd>
 __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
+    __shared__ float part[4][64];
     const int g = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= kSmallTotal) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     float* gr = c.grad + g * c.grad_stride;
     const int nv = c.nvalid[g * c.nvalid_stride + step];
     int dst = -1;      // arena offset of the parameter this thread owns
     int w2t_at = -1;   // conv2.weight only: position in the [tap][c][oc] copy
-    float s;
+    int metric = -1;
+    const float* src = nullptr;
+    int count = 0;
+    long stride = 0;
     if (e < kConv1Part) {
-        const int slabs = c.B * c.split;
-        s = sum_slabs(c.conv1_part + static_cast<long>(g) * slabs * kConv1Part + e, slabs,
-                      kConv1Part);
+        count = c.B * c.split;
+        stride = kConv1Part;
+        src = c.conv1_part + static_cast<long>(g) * count * kConv1Part + e;
         dst = e < 288 ? c.off_c1w + e : c.off_c1b + e - 288;
     } else if (e < kConv1Part + kConv2Part) {
         const int e2 = e - kConv1Part;
-        s = sum_slabs(c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2, c.WPC,
-                      kConv2Part);
+        count = c.WPC;
+        stride = kConv2Part;
+        src = c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2;
         dst = c.off_c2w + e2;
         const int oc = e2 / 288;
         w2t_at = (e2 - oc * 288) * 64 + oc;
     } else if (e < kConv1Part + kConv2Part + 64) {
         const int e2 = e - kConv1Part - kConv2Part;
-        s = sum_slabs(c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2, kFc1Tiles, 64);
+        count = kFc1Tiles;
+        stride = 64;
+        src = c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2;
         dst = c.off_c2b + e2;
-    } else {
+    } else if (e < kSmallTotal) {
         const int e3 = e - kConv1Part - kConv2Part - 64;
-        const int hbn = c.B / kHeadRows;
-        s = sum_slabs(c.head_part + static_cast<long>(g) * hbn * kHeadPart + e3, hbn, kHeadPart);
+        count = c.B / kHeadRows;
+        stride = kHeadPart;
+        src = c.head_part + static_cast<long>(g) * count * kHeadPart + e3;
         if (e3 < 1280) dst = c.off_f2w + e3;
         else if (e3 < 1290) dst = c.off_f2b + e3 - 1280;
         else if (e3 >= 1296 && e3 < 1424) dst = c.off_f1b + e3 - 1296;
-        else if (e3 == 1424 || e3 == 1425) {
-            if (nv > 0) {
-                float* m = c.metrics + g * 4;
-                if (e3 == 1424) { m[0] += s / nv; m[2] += 1.0f; }
-                else m[1] += s / nv;
-            }
-        }
+        else if (e3 == 1424 || e3 == 1425) metric = e3 - 1424;
+    }
+    float* p = c.arena + g * c.arena_stride + (dst >= 0 ? dst : 0);
+    const float pv = (kSgd && wave == 0) ? *p : 0.f;  // in flight during the sums
+    float s = src != nullptr ? sum_slabs(src, count, stride, wave) : 0.f;
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0) return;
+    s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (metric >= 0 && nv > 0) {
+        float* m = c.metrics + g * 4;
+        if (metric == 0) { m[0] += s / nv; m[2] += 1.0f; }
+        else m[1] += s / nv;
     }
     if (dst >= 0) gr[dst] = s;
     if (kSgd && nv > 0) {
         if (dst >= 0) {
-            float* p = c.arena + g * c.arena_stride + dst;
-            const float v = *p - c.lr * fmaf(c.wd, *p, s);
+            const float v = pv - c.lr * fmaf(c.wd, pv, s);
             *p = v;
             const bf16 h = f2bf(v);
             c.shadow[g * c.shadow_stride + dst] = h;
@@ -1146,10 +1160,10 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     case 5: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c, step); break;
     case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, split_grid, dim3(256), kDgLds, s, *c, idx_off); break;
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
-    case 8: hipLaunchKernelGGL(finalize_kernel<false>, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step); break;
+    case 8: hipLaunchKernelGGL(finalize_kernel<false>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step); break;
     case 12:
         if (!c->fuse_sgd || c->dp_pass != 0) return -12;
-        hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 255) / 256, c->G), dim3(256), 0, s, *c, step);
+        hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step);
         break;
     case 9:
         hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0);

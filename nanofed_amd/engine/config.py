@@ -61,6 +61,16 @@ class EngineConfig:
     min_completion_rate: float = 1.0
     validate_updates: bool = True
     max_update_norm: float = 0.0  # 0 disables the norm bound (finite check stays)
+    # a client that reports later than this many seconds is left out of the round
+    # (reference: CoordinatorConfig.round_timeout); 0 = wait for everybody
+    round_timeout_s: float = 0.0
+    # fault tolerance: write a FileStateStore checkpoint after every completed
+    # round and roll back to the last one on a recoverable failure
+    checkpoint_rounds: bool = False
+    max_recoveries: int = 2
+    # observability: HIP-event timing of the round's phases (extra key
+    # "phases_ms" in the round metrics JSON)
+    phase_timing: bool = True
     # privacy
     dp: DPConfig | None = None
     seed: int = 0

@@ -46,6 +46,7 @@ from nanofed_amd.models import build_model
 from nanofed_amd.parallel.comm import Communicator
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool, ParameterArena
 from nanofed_amd.utils import Logger, get_current_time
+from nanofed_amd.utils.trace import PhaseTimer
 
 from .config import EngineConfig
 from .data import DeviceShards, FederatedData, build_federated_data
@@ -79,10 +80,15 @@ class RoundReport:
 class FaultPlan:
     """Fault injection for tests and drills: ``drop[r]`` = client ids that
     submit nothing in round r; ``poison[r]`` = client ids whose update is
-    overwritten with NaNs before screening."""
+    overwritten with NaNs before screening; ``delay[r]`` = {client id: seconds
+    the client reports late} (left out when later than ``round_timeout_s``);
+    ``fail[r]`` = message of a ``RuntimeError`` raised once in the middle of
+    round r, the way a HIP or RCCL error would surface."""
 
     drop: dict[int, set[int]] = field(default_factory=dict)
     poison: dict[int, set[int]] = field(default_factory=dict)
+    delay: dict[int, dict[int, float]] = field(default_factory=dict)
+    fail: dict[int, str] = field(default_factory=dict)
 
 
 def clients_of_rank(num_clients: int, world: int, rank: int) -> list[int]:
@@ -153,6 +159,9 @@ class FederatedEngine:
         self._screen = torch.zeros(len(self.client_ids), 2, dtype=torch.float32, device=self.device)
         self._delta = torch.zeros(self.layout.numel, dtype=torch.float32, device=self.device)
         self._model_manager = None
+        self._recovery = None
+        self.recoveries = 0
+        self._timer = PhaseTimer(self.device)
         if self.base_dir is not None and self.comm.is_root:
             self._setup_persistence()
         self._K = K
@@ -189,6 +198,10 @@ class FederatedEngine:
             (base / sub).mkdir(parents=True, exist_ok=True)
         self._model_manager = ModelManager(self._host_model)
         self._model_manager.set_dirs(base / "models" / "models", base / "models" / "configs")
+        if self.cfg.checkpoint_rounds:
+            from nanofed_amd.server.fault_tolerance import FaultTolerantCoordinator
+
+            self._recovery = FaultTolerantCoordinator(base)
 
     # -- the round --------------------------------------------------------
     def run_round(self) -> RoundReport:
@@ -197,53 +210,69 @@ class FederatedEngine:
         t0 = time.perf_counter()
         start = get_current_time()
 
+        timer = self._timer
         # 1. broadcast
-        self.pool.broadcast_from(self.global_arena.data)
+        with timer.phase("broadcast"):
+            self.pool.broadcast_from(self.global_arena.data)
         # 2. local training
-        local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
+        with timer.phase("local_train"):
+            local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
         # fault injection
+        if r in self.faults.fail:
+            raise RuntimeError(self.faults.fail.pop(r))
+        late = {
+            cid for cid, secs in self.faults.delay.get(r, {}).items()
+            if cfg.round_timeout_s > 0 and secs > cfg.round_timeout_s
+        }
         for k, cid in enumerate(self.client_ids):
             if cid in self.faults.poison.get(r, ()):
                 self.pool[k].data.fill_(float("nan"))
-            if cid in self.faults.drop.get(r, ()):
+            if cid in self.faults.drop.get(r, ()) or cid in late:
                 local[k, M_VALID] = 0.0
-        # 3. screening -> participation mask
-        if cfg.validate_updates:
-            self._screen_updates(local)
-        # 4. gather the per-client records
-        self._local_records.zero_()
-        self._local_records[: len(self.client_ids)].copy_(local)
-        gathered = comm.allgather(self._local_records)  # [W, max_local, M]
-        records = torch.cat(
-            [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
-        )  # [K, M] in client-id order
-        # 5. weights on device
-        mask = records[:, M_VALID]
-        mass = mask * records[:, M_SAMPLES]
-        total = mass.sum()
-        weights = mass / total.clamp(min=1e-30)
-        n_valid = mask.sum()
-        ok = (n_valid >= float(cfg.required_clients())) & (total > 0)
-        lo = self.client_ids[0]
-        w_local = weights[lo : lo + len(self.client_ids)]
-        # 6. FedAvg: fused local weighted sum + one all-reduce (rows with
-        #    weight 0 are never read, so a poisoned row cannot leak NaNs)
-        ops.weighted_sum(self.pool.rows(), w_local, out=self._partial)
-        comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
-        # 7. quorum select (device-side; the old model survives a failed round)
-        self.global_arena.data.copy_(
-            torch.where(ok, self._partial, self.global_arena.data)
-        )
+        with timer.phase("screen_gather"):
+            # 3. screening -> participation mask
+            if cfg.validate_updates:
+                self._screen_updates(local)
+            # 4. gather the per-client records
+            self._local_records.zero_()
+            self._local_records[: len(self.client_ids)].copy_(local)
+            gathered = comm.allgather(self._local_records)  # [W, max_local, M]
+            records = torch.cat(
+                [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
+            )  # [K, M] in client-id order
+        with timer.phase("reduce"):
+            # 5. weights on device
+            mask = records[:, M_VALID]
+            mass = mask * records[:, M_SAMPLES]
+            total = mass.sum()
+            weights = mass / total.clamp(min=1e-30)
+            n_valid = mask.sum()
+            ok = (n_valid >= float(cfg.required_clients())) & (total > 0)
+            lo = self.client_ids[0]
+            w_local = weights[lo : lo + len(self.client_ids)]
+            # 6. FedAvg: fused local weighted sum + one all-reduce (rows with
+            #    weight 0 are never read, so a poisoned row cannot leak NaNs)
+            ops.weighted_sum(self.pool.rows(), w_local, out=self._partial)
+            comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
+            # 7. quorum select (device-side; the old model survives a failed round)
+            self.global_arena.data.copy_(
+                torch.where(ok, self._partial, self.global_arena.data)
+            )
         # 8. the only host synchronisation of the round
         host = torch.cat([records.reshape(-1), ok.float().reshape(1)]).cpu()
         rec = host[:-1].view(-1, METRIC_COLUMNS).numpy()
         succeeded = bool(host[-1] > 0)
+        phases = timer.collect() if cfg.phase_timing else {}
 
         report = self._report(r, rec, succeeded, start, time.perf_counter() - t0)
+        report.phases_ms = phases
         self.reports.append(report)
         if succeeded:
             self.round_id += 1
+            t_ck = time.perf_counter()
             self._persist(report)
+            if self._model_manager is not None:
+                report.phases_ms["checkpoint"] = (time.perf_counter() - t_ck) * 1000.0
         return report
 
     def _screen_updates(self, local: torch.Tensor) -> None:
@@ -331,16 +360,84 @@ class FederatedEngine:
                     "agg_metrics": report.agg_metrics,
                     "status": report.status,
                     "client_metrics": report.client_metrics,
+                    "phases_ms": report.phases_ms,
                 },
                 f, indent=4,
+            )
+        if self._recovery is not None:
+            from nanofed_amd.server.fault_tolerance import RoundState
+
+            version = self._model_manager.current_version
+            self._recovery.checkpoint_round(
+                report.round_id,
+                {},  # client models stay on the device; the global state is enough to resume
+                version.version_id if version is not None else "",
+                {"model_state": self.global_state_dict(), "next_round": self.round_id},
+                RoundState.COMPLETED,
             )
 
     # -- public helpers ---------------------------------------------------
     def run(self, num_rounds: int | None = None) -> list[RoundReport]:
-        out = []
-        for _ in range(num_rounds if num_rounds is not None else self.cfg.num_rounds):
-            out.append(self.run_round())
+        """Run rounds until ``num_rounds`` more have COMPLETED or FAILED on
+        quorum.  A recoverable exception inside a round (``RuntimeError`` is how
+        HIP and RCCL errors surface; reference: nanofed/server/fault_tolerance.py
+        :139-152) rolls the global model back to the last completed checkpoint and
+        repeats from there, at most ``max_recoveries`` times."""
+        out: list[RoundReport] = []
+        target = num_rounds if num_rounds is not None else self.cfg.num_rounds
+        while len(out) < target:
+            try:
+                out.append(self.run_round())
+            except Exception as failure:  # noqa: BLE001 - the strategy decides
+                if not self._recover(failure):
+                    raise
         return out
+
+    def _recover(self, failure: Exception) -> bool:
+        """Every rank takes the same decision: rank 0 owns the checkpoints, the
+        restored arena and round counter are broadcast."""
+        if not self.cfg.checkpoint_rounds or self.recoveries >= self.cfg.max_recoveries:
+            return False
+        self.recoveries += 1
+        self._timer.collect()
+        flag = torch.zeros(2, dtype=torch.float32, device=self.device)
+        if self.comm.is_root and self._recovery is not None:
+            restored = self._recovery.handle_failure(failure, self.round_id)
+            if restored is not None:
+                _, state = restored
+                self.global_arena.load_state_dict(state["model_state"])
+                flag[0] = 1.0
+                flag[1] = float(state.get("next_round", self.round_id))
+            elif self._recovery._recovery.should_recover(failure):
+                # nothing completed yet: the untouched initial model is the recovery point
+                flag[0] = 1.0
+                flag[1] = float(self.round_id)
+        self.comm.broadcast(flag, src=0)
+        if float(flag[0]) == 0.0:
+            return False
+        self.comm.broadcast(self.global_arena.data, src=0)
+        self.round_id = int(flag[1])
+        self.logger.warning(
+            f"Recovered from {type(failure).__name__}: {failure}; resuming at round {self.round_id}"
+        )
+        return True
+
+    def resume(self) -> int:
+        """Continue a run from ``base_dir``: load the newest ModelManager version
+        and take the round counter from its config (the reference always
+        restarts at round 0, nanofed/server/model_manager/manager.py:144-188).
+        Returns the round the engine will run next."""
+        state = torch.zeros(1, dtype=torch.float32, device=self.device)
+        if self.comm.is_root and self._model_manager is not None:
+            versions = self._model_manager.list_versions()
+            if versions:
+                version = self._model_manager.load_model()
+                self.global_arena.load_state_dict(self._host_model.state_dict())
+                state[0] = float(version.config.get("round_id", -1) + 1)
+        self.comm.broadcast(state, src=0)
+        self.comm.broadcast(self.global_arena.data, src=0)
+        self.round_id = int(state[0])
+        return self.round_id
 
     def evaluate(self) -> dict[str, float]:
         return self.trainer.evaluate(self.global_arena.data)
