@@ -53,6 +53,7 @@ class Communicator:
         device: torch.device | None = None,
         group: dist.ProcessGroup | None = None,
         owns_group: bool = False,
+        force_collectives: bool = False,
     ) -> None:
         self.rank = rank
         self.world_size = world_size
@@ -61,6 +62,8 @@ class Communicator:
         self.device = device or torch.device("cpu")
         self.group = group
         self._owns_group = owns_group
+        # a world of one skips every collective unless this is set
+        self._single = world_size == 1 and not (force_collectives and group is not None)
         self._pad: dict[int, torch.Tensor] = {}
 
     # -- construction -----------------------------------------------------
@@ -87,7 +90,11 @@ class Communicator:
             torch.cuda.set_device(device)
         if backend is None:
             backend = "nccl" if device.type == "cuda" else "gloo"
-        if world == 1:
+        # NANOFED_FORCE_GROUP=1 builds the process group even for a single rank, so
+        # the collectives really go through RCCL / gloo (a one-GPU rehearsal of the
+        # multi-GPU code path)
+        force = os.environ.get("NANOFED_FORCE_GROUP", "0") == "1"
+        if world == 1 and not force:
             return cls(0, 1, local_rank, None, device)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -101,7 +108,7 @@ class Communicator:
                 timeout=datetime.timedelta(seconds=timeout_s), **kwargs,
             )
             owns = True
-        return cls(rank, world, local_rank, backend, device, dist.group.WORLD, owns)
+        return cls(rank, world, local_rank, backend, device, dist.group.WORLD, owns, force)
 
     def close(self) -> None:
         if self._owns_group and dist.is_initialized():
@@ -126,7 +133,7 @@ class Communicator:
 
     # -- collectives ------------------------------------------------------
     def barrier(self) -> None:
-        if self.world_size == 1:
+        if self._single:
             return
         if self.backend == "nccl":
             dist.barrier(group=self.group, device_ids=[self.device.index or 0])
@@ -134,7 +141,7 @@ class Communicator:
             dist.barrier(group=self.group)
 
     def broadcast(self, flat: torch.Tensor, src: int = 0) -> torch.Tensor:
-        if self.world_size > 1:
+        if not self._single:
             self._run(flat, lambda t: dist.broadcast(t, src=src, group=self.group))
         return flat
 
@@ -149,7 +156,7 @@ class Communicator:
         1/world slice between reduce-scatter and all-gather (``rs_ag`` only)."""
         if algo not in ("auto", "allreduce", "rs_ag"):
             raise DeviceError(f"unknown all-reduce algorithm {algo!r}")
-        if self.world_size == 1:
+        if self._single:
             if shard_hook is not None:
                 shard_hook(flat, 0)
             return flat
@@ -191,7 +198,7 @@ class Communicator:
 
     def allgather(self, local: torch.Tensor) -> torch.Tensor:
         """``[world, *local.shape]`` stack of every rank's tensor."""
-        if self.world_size == 1:
+        if self._single:
             return local.unsqueeze(0).clone()
         staged = self._host_staged(local)
         src = local.detach().to("cpu") if staged else local.contiguous()
@@ -202,7 +209,7 @@ class Communicator:
         return out.to(local.device) if staged else out
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world_size == 1:
+        if self._single:
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64)
         if self.backend == "nccl":

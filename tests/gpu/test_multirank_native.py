@@ -57,3 +57,44 @@ def test_two_ranks_equal_one_rank(tmp_path):
     # in the last bit, and early SGD at lr 0.1 amplifies that)
     torch.testing.assert_close(dist["flat"], single.global_arena.data.cpu(), rtol=1e-5, atol=1e-6)
     assert dist["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-3)
+
+
+RCCL_WORKER = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from nanofed_amd.engine import EngineConfig, FederatedEngine
+from nanofed_amd.parallel import Communicator
+comm = Communicator.from_env()          # nccl (= RCCL) on cuda:0, group forced by the env
+assert comm.backend == "nccl" and comm.group is not None and not comm._single
+cfg = dict({cfg!r}, reduce_algo={algo!r})
+eng = FederatedEngine(EngineConfig(**cfg), comm=comm)
+reps = eng.run(2)
+comm.barrier()
+t = comm.max_over_ranks(1.5)
+torch.cuda.synchronize()
+torch.save({{"flat": eng.global_arena.data.cpu(), "loss": reps[-1].agg_metrics["loss"], "max": t}},
+           {out!r})
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_rccl_collectives_single_rank_rehearsal(tmp_path, algo):
+    """Every collective of the round goes through a real RCCL communicator (a
+    group of one rank): broadcast, all-gather of the records, all-reduce or
+    reduce-scatter + all-gather of the arena, barrier, max."""
+    out = tmp_path / f"rccl_{algo}.pt"
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT, cfg=CFG, out=str(out), algo=algo))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", NANOFED_FORCE_GROUP="1")
+    proc = subprocess.run([sys.executable, str(script)], capture_output=True, text=True,
+                          timeout=280, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    got = torch.load(out, weights_only=True)
+    torch.cuda.set_device(0)
+    single = FederatedEngine(EngineConfig(**CFG), comm=Communicator(device=torch.device("cuda", 0)))
+    reps = single.run(2)
+    assert got["max"] == 1.5
+    torch.testing.assert_close(got["flat"], single.global_arena.data.cpu(), rtol=0, atol=0)
+    assert got["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-6)
