@@ -1,4 +1,4 @@
-.PHONY: install build test test-gpu lint format clean bench docs changelog release-prepare release
+.PHONY: install build test test-gpu lint format format-check host-sanitize clean bench docs changelog release-prepare release
 
 install:
 	python -m pip install -e . --no-build-isolation --no-deps
@@ -19,6 +19,14 @@ lint:
 format:
 	@command -v ruff >/dev/null && ruff format nanofed_amd tests || echo "ruff not installed"
 
+format-check:
+	@command -v ruff >/dev/null && ruff format --check nanofed_amd tests || echo "ruff not installed"
+
+# AddressSanitizer + UBSan build of the host library and its C++ self-test
+# (GPU sanitizers are not used: host code only)
+host-sanitize:
+	bash tools/host_sanitize.sh
+
 bench: build
 	python bench.py
 
@@ -27,7 +35,7 @@ clean:
 	find . -name __pycache__ -type d -prune -exec rm -rf {} +
 
 docs:
-	@echo "documentation lives in docs/*.md, DESIGN.md and README.md"
+	@command -v mkdocs >/dev/null && mkdocs build || echo "mkdocs not installed: documentation lives in docs/*.md, DESIGN.md and README.md"
 
 changelog:
 	python scripts/changelog.py
