@@ -133,7 +133,7 @@ class FederatedEngine:
         self._model_factory = lambda: build_model(cfg.model, **cfg.model_kwargs)
         self._host_model = self._model_factory()
         self.backend = self._resolve_backend()
-        if self.backend == "native":
+        if self.backend == "native" and cfg.model == "mnist_cnn":
             from .mnist_native import make_layout
 
             self.layout = make_layout(self._host_model)
@@ -171,10 +171,16 @@ class FederatedEngine:
         cfg = self.cfg
         if factory is not None:
             return factory(cfg, self.pool, self.shards, self._model_factory, self.data)
-        if self.backend == "native":
+        if self.backend == "native" and cfg.model == "mnist_cnn":
             from .mnist_native import MnistCnnNativeTrainer
 
             return MnistCnnNativeTrainer(cfg, self.pool, self.shards, self.data)
+        if self.backend == "native" and cfg.model.startswith("gpt2"):
+            from .gpt2_native import GPT2NativeTrainer
+
+            return GPT2NativeTrainer(cfg, self.pool, self.shards, self.data, self._host_model.cfg)
+        if self.backend == "native":
+            raise DeviceError(f"no native trainer for model {cfg.model!r}")
         return TorchGroupTrainer(
             cfg, self.pool, self.shards, self._model_factory,
             self.data.eval_inputs, self.data.eval_labels,
@@ -184,11 +190,19 @@ class FederatedEngine:
         cfg = self.cfg
         if cfg.backend != "auto":
             return cfg.backend
-        native_ok = (
-            cfg.model == "mnist_cnn" and self.device.type == "cuda"
+        on_gpu = self.device.type == "cuda"
+        mnist_ok = (
+            cfg.model == "mnist_cnn" and on_gpu
             and (cfg.dp is None or cfg.dp.mode == "per_sample") and cfg.batch_size == 64
         )
-        return "native" if native_ok else "torch"
+        gpt2_ok = False
+        if cfg.model.startswith("gpt2") and on_gpu and cfg.dp is None and cfg.dtype == "bf16":
+            m = self._host_model.cfg
+            gpt2_ok = (
+                m.n_embd == 64 * m.n_head and m.dropout == 0.0 and cfg.seq_len % 128 == 0
+                and m.n_embd <= 2048
+            )
+        return "native" if (mnist_ok or gpt2_ok) else "torch"
 
     def _setup_persistence(self) -> None:
         from nanofed_amd.server.model_manager import ModelManager

@@ -1,0 +1,265 @@
+"""Local trainer of the GPT-2 configuration with an explicit forward/backward.
+
+The model is ``nanofed_amd.models.gpt2.GPT2LM`` (the reference has no sequence
+model; its training step is nanofed/trainer/base.py:141-159: zero_grad,
+forward, loss, backward, SGD).  Instead of autograd under bf16 autocast this
+trainer runs the step by hand on flat buffers:
+
+* fp32 master weights stay in the client's arena row; the forward and backward
+  passes read a bf16 copy with the same offsets, refreshed by the SGD kernel, so
+  no weight is cast per step;
+* gradients are written as bf16 straight into one flat gradient buffer by the
+  GEMMs (``torch.mm(..., out=view)``), then consumed by one SGD launch;
+* everything between the GEMMs is a hand-written kernel
+  (``nanofed_amd.ops.nn_ops`` / ``nanofed_amd.ops.attention``): embedding
+  gather and its scatter-free backward, residual-add + LayerNorm, tanh-GELU,
+  bias gradients, softmax cross-entropy that overwrites the logits with their
+  gradient (the logits are never upcast), causal flash attention;
+* GEMMs go to hipBLASLt through ``torch.mm`` / ``torch.addmm`` (bias in the
+  GEMM epilogue).
+
+Activations are bf16, statistics and losses fp32.  The G clients of a GPU are
+trained one after the other and share the activation and gradient buffers.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from nanofed_amd.core.exceptions import DeviceError
+from nanofed_amd.models.gpt2 import GPT2Config
+from nanofed_amd.ops import attention as attn_ops
+from nanofed_amd.ops import nn_ops
+from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
+
+from .config import EngineConfig
+from .data import DeviceShards, FederatedData
+from .trainers import M_ACC, M_LOSS, M_SAMPLES, M_VALID, METRIC_COLUMNS, GroupTrainer
+
+BF16 = torch.bfloat16
+
+
+def _views(layout: ArenaLayout, flat: torch.Tensor) -> dict[str, torch.Tensor]:
+    return {s.name: flat[s.offset : s.offset + s.numel].view(s.shape) for s in layout.segments}
+
+
+class _Buffers:
+    """Activations of one step for ``R = batch * seq`` rows."""
+
+    def __init__(self, m: GPT2Config, batch: int, seq: int, device: torch.device) -> None:
+        R, C, L = batch * seq, m.n_embd, m.n_layer
+        self.R, self.batch, self.seq = R, batch, seq
+        self.ld = (m.vocab_size + 63) // 64 * 64
+
+        def bf(*shape):
+            return torch.empty(*shape, dtype=BF16, device=device)
+
+        def f32(*shape):
+            return torch.empty(*shape, dtype=torch.float32, device=device)
+
+        self.x = bf(L + 1, R, C)       # input of every block, and of ln_f
+        self.x_mid = bf(L, R, C)       # after the attention residual
+        self.ln1, self.ln2 = bf(L, R, C), bf(L, R, C)
+        self.qkv = bf(L, R, 3 * C)
+        self.att = bf(L, R, C)
+        self.lse = f32(L, batch, m.n_head, seq)
+        self.fc, self.act = bf(L, R, 4 * C), bf(L, R, 4 * C)
+        self.stats = f32(2 * L + 1, 2, R)  # mean / rstd of ln_1, ln_2 per layer and ln_f
+        self.lnf = bf(R, C)
+        self.tmp_c = bf(R, C)
+        self.logits = bf(R, self.ld)
+        self.loss_rows, self.correct_rows = f32(R), f32(R)
+        # backward scratch
+        self.dres, self.dln, self.datt = bf(R, C), bf(R, C), bf(R, C)
+        self.dact = bf(R, 4 * C)
+        self.dqkv = bf(R, 3 * C)
+        self.attn_scratch = attn_ops.backward_scratch(batch, m.n_head, seq, device)
+
+
+class GPT2NativeTrainer(GroupTrainer):
+    def __init__(
+        self,
+        cfg: EngineConfig,
+        pool: ArenaPool,
+        shards: DeviceShards,
+        data: FederatedData,
+        model_cfg: GPT2Config,
+    ) -> None:
+        if cfg.dp is not None:
+            raise DeviceError("the GPT-2 trainer has no DP-SGD path")
+        if model_cfg.dropout != 0.0:
+            raise DeviceError("the GPT-2 trainer does not implement dropout")
+        if model_cfg.n_embd % model_cfg.n_head or (model_cfg.n_embd // model_cfg.n_head) != 64:
+            raise DeviceError("the attention kernels need a head dimension of 64")
+        self.cfg, self.pool, self.shards, self.m = cfg, pool, shards, model_cfg
+        self.layout = pool.layout
+        self.device = pool.data.device
+        G = len(pool)
+        n = self.layout.numel
+        self.shadow = torch.zeros(G, n, dtype=BF16, device=self.device)
+        self.grad = torch.zeros(n, dtype=BF16, device=self.device)
+        self._gv = _views(self.layout, self.grad)
+        self._eval_shadow = torch.zeros(n, dtype=BF16, device=self.device)
+        self._bufs: dict[tuple[int, int], _Buffers] = {}
+        self._eval_inputs = data.eval_inputs
+        # the kernels index the embedding table with the raw ids: check them once
+        for toks in (shards.inputs, data.eval_inputs):
+            if toks is not None and toks.numel() and (
+                int(toks.max()) >= model_cfg.vocab_size or int(toks.min()) < 0
+            ):
+                raise DeviceError("token id outside the vocabulary")
+        self.metrics = torch.zeros(G, METRIC_COLUMNS, dtype=torch.float32, device=self.device)
+        self._acc = torch.zeros(G, 3, dtype=torch.float32, device=self.device)
+
+    # -- buffers ------------------------------------------------------------
+    def _buffers(self, batch: int, seq: int) -> _Buffers:
+        key = (batch, seq)
+        if key not in self._bufs:
+            self._bufs[key] = _Buffers(self.m, batch, seq, self.device)
+        return self._bufs[key]
+
+    # -- forward ------------------------------------------------------------
+    def _forward(self, w: dict[str, torch.Tensor], tokens: torch.Tensor, b: _Buffers) -> None:
+        """Fills the activation buffers and leaves d(logits) in ``b.logits``,
+        per-row losses in ``b.loss_rows``."""
+        m, L = self.m, self.m.n_layer
+        inp = tokens[:, :-1].contiguous().view(-1)
+        tgt = tokens[:, 1:].contiguous().view(-1)
+        V = m.vocab_size
+        nn_ops.embed_fwd(inp, w["wte.weight"], w["wpe.weight"], b.seq, out=b.x[0])
+        delta = None
+        for l in range(L):
+            p = f"h.{l}."
+            st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
+            if l == 0:
+                nn_ops.ln_fwd(b.x[0], w[p + "ln_1.weight"], w[p + "ln_1.bias"], b.ln1[0],
+                              st1[0], st1[1])
+            else:
+                nn_ops.ln_fwd(b.x_mid[l - 1], w[p + "ln_1.weight"], w[p + "ln_1.bias"],
+                              b.ln1[l], st1[0], st1[1], delta=delta, x_out=b.x[l])
+            torch.addmm(w[p + "attn.c_attn.bias"], b.ln1[l], w[p + "attn.c_attn.weight"].t(),
+                        out=b.qkv[l])
+            attn_ops.causal_attention_fwd(b.qkv[l], b.att[l], b.lse[l], b.batch, b.seq, m.n_head)
+            torch.addmm(w[p + "attn.c_proj.bias"], b.att[l], w[p + "attn.c_proj.weight"].t(),
+                        out=b.tmp_c)
+            nn_ops.ln_fwd(b.x[l], w[p + "ln_2.weight"], w[p + "ln_2.bias"], b.ln2[l],
+                          st2[0], st2[1], delta=b.tmp_c, x_out=b.x_mid[l])
+            torch.addmm(w[p + "c_fc.bias"], b.ln2[l], w[p + "c_fc.weight"].t(), out=b.fc[l])
+            nn_ops.gelu_fwd(b.fc[l], b.act[l])
+            torch.addmm(w[p + "c_proj.bias"], b.act[l], w[p + "c_proj.weight"].t(), out=b.tmp_c)
+            delta = b.tmp_c
+        stf = b.stats[2 * L]
+        nn_ops.ln_fwd(b.x_mid[L - 1], w["ln_f.weight"], w["ln_f.bias"], b.lnf, stf[0], stf[1],
+                      delta=delta, x_out=b.x[L])
+        torch.mm(b.lnf, w["wte.weight"].t(), out=b.logits[:, :V])
+        nn_ops.cross_entropy_fwd_bwd(b.logits, tgt, V, 1.0 / b.R, b.loss_rows, b.correct_rows)
+
+    # -- backward -----------------------------------------------------------
+    def _backward(self, w: dict[str, torch.Tensor], tokens: torch.Tensor, b: _Buffers) -> None:
+        m, L, g = self.m, self.m.n_layer, self._gv
+        V = m.vocab_size
+        dlog = b.logits[:, :V]
+        torch.mm(dlog.t(), b.lnf, out=g["wte.weight"])  # LM head shares the embedding matrix
+        torch.mm(dlog, w["wte.weight"], out=b.dln)
+        stf = b.stats[2 * L]
+        nn_ops.ln_bwd(b.dln, b.x[L], w["ln_f.weight"], stf[0], stf[1], b.dres,
+                      g["ln_f.weight"], g["ln_f.bias"])
+        for l in reversed(range(L)):
+            p = f"h.{l}."
+            st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
+            # MLP: x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
+            nn_ops.colsum(b.dres, g[p + "c_proj.bias"])
+            torch.mm(b.dres.t(), b.act[l], out=g[p + "c_proj.weight"])
+            torch.mm(b.dres, w[p + "c_proj.weight"], out=b.dact)
+            nn_ops.gelu_bwd(b.fc[l], b.dact, b.dact)
+            nn_ops.colsum(b.dact, g[p + "c_fc.bias"])
+            torch.mm(b.dact.t(), b.ln2[l], out=g[p + "c_fc.weight"])
+            torch.mm(b.dact, w[p + "c_fc.weight"], out=b.dln)
+            nn_ops.ln_bwd(b.dln, b.x_mid[l], w[p + "ln_2.weight"], st2[0], st2[1], b.dres,
+                          g[p + "ln_2.weight"], g[p + "ln_2.bias"], dres=b.dres)
+            # attention: x_mid = x + c_proj(attn(c_attn(ln_1(x))))
+            nn_ops.colsum(b.dres, g[p + "attn.c_proj.bias"])
+            torch.mm(b.dres.t(), b.att[l], out=g[p + "attn.c_proj.weight"])
+            torch.mm(b.dres, w[p + "attn.c_proj.weight"], out=b.datt)
+            attn_ops.causal_attention_bwd(b.qkv[l], b.att[l], b.lse[l], b.datt, b.dqkv,
+                                          b.attn_scratch, b.batch, b.seq, m.n_head)
+            nn_ops.colsum(b.dqkv, g[p + "attn.c_attn.bias"])
+            torch.mm(b.dqkv.t(), b.ln1[l], out=g[p + "attn.c_attn.weight"])
+            torch.mm(b.dqkv, w[p + "attn.c_attn.weight"], out=b.dln)
+            nn_ops.ln_bwd(b.dln, b.x[l], w[p + "ln_1.weight"], st1[0], st1[1], b.dres,
+                          g[p + "ln_1.weight"], g[p + "ln_1.bias"], dres=b.dres)
+        nn_ops.embed_bwd(tokens[:, :-1].contiguous(), b.dres, g["wte.weight"], g["wpe.weight"],
+                         b.batch, b.seq)
+
+    # -- one optimisation step of client k ------------------------------------
+    def _step(self, k: int, tokens: torch.Tensor) -> None:
+        cfg = self.cfg
+        b = self._buffers(tokens.shape[0], tokens.shape[1] - 1)
+        w = _views(self.layout, self.shadow[k])
+        self._forward(w, tokens, b)
+        self._backward(w, tokens, b)
+        nn_ops.sgd_step_bf16g(self.pool[k].data, self.grad, self.shadow[k], cfg.learning_rate,
+                              cfg.weight_decay)
+        acc = self._acc[k]
+        acc[0] += b.loss_rows.mean()
+        acc[1] += b.correct_rows.mean()
+        acc[2] += 1.0
+
+    def loss_and_grads(self, k: int, tokens: torch.Tensor) -> tuple[float, dict[str, torch.Tensor]]:
+        """Loss and the flat gradient views of one batch, without an update
+        (the kernel tests compare these with autograd)."""
+        b = self._buffers(tokens.shape[0], tokens.shape[1] - 1)
+        self.shadow[k].copy_(self.pool[k].data)
+        w = _views(self.layout, self.shadow[k])
+        self._forward(w, tokens, b)
+        self._backward(w, tokens, b)
+        return float(b.loss_rows.mean()), self._gv
+
+    def train_round(self, round_idx: int) -> torch.Tensor:
+        cfg = self.cfg
+        self.metrics.zero_()
+        for k in range(len(self.pool)):
+            self.shadow[k].copy_(self.pool[k].data)  # the round starts from the broadcast model
+            for epoch in range(cfg.local_epochs):
+                self._acc[k].zero_()
+                perm = self.shards.epoch_permutation(k, round_idx, epoch)
+                for s in range(self.shards.steps_per_epoch(k)):
+                    rows = perm[s * cfg.batch_size : (s + 1) * cfg.batch_size]
+                    self._step(k, self.shards.inputs[rows])
+            batches = self._acc[k, 2].clamp(min=1.0)
+            self.metrics[k, M_SAMPLES] = float(self.shards.sizes[k])
+            self.metrics[k, M_LOSS] = self._acc[k, 0] / batches
+            self.metrics[k, M_ACC] = self._acc[k, 1] / batches
+            self.metrics[k, M_VALID] = 1.0
+        return self.metrics
+
+    @torch.no_grad()
+    def evaluate(self, flat: torch.Tensor, batch: int = 4) -> dict[str, float]:
+        if self._eval_inputs is None or len(self._eval_inputs) == 0:
+            return {}
+        self._eval_shadow.copy_(flat)
+        w = _views(self.layout, self._eval_shadow)
+        xs = self._eval_inputs.to(self.device)
+        loss = torch.zeros((), device=self.device)
+        hits = torch.zeros((), device=self.device)
+        rows = 0
+        for lo in range(0, len(xs), batch):
+            toks = xs[lo : lo + batch]
+            b = self._buffers(toks.shape[0], toks.shape[1] - 1)
+            self._forward(w, toks, b)
+            loss += b.loss_rows.sum()
+            hits += b.correct_rows.sum()
+            rows += b.R
+        return {"loss": float(loss) / rows, "accuracy": float(hits) / rows,
+                "samples": float(len(xs))}
+
+
+def reference_attention(qkv: torch.Tensor, batch: int, seq: int, heads: int) -> torch.Tensor:
+    """``[R, C]`` attention output of a packed ``[R, 3C]`` q|k|v matrix through
+    PyTorch (fp32) - the oracle of the attention kernel tests."""
+    C = qkv.shape[1] // 3
+    q, k, v = qkv.float().view(batch, seq, 3, heads, C // heads).unbind(2)
+    y = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                                       is_causal=True)
+    return y.transpose(1, 2).reshape(batch * seq, C)
