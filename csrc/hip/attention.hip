@@ -189,19 +189,28 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16* qkv, bf16* ou
 }
 
 // ---------------------------------------------------------------------------
-// One wave per (row, head): delta = sum_d dO * O.
+// Eight lanes per (row, head), 8 values each: delta = sum_d dO * O.
 __global__ void __launch_bounds__(256) attn_bwd_delta_kernel(const bf16* out, const bf16* dout,
                                                              float* delta, int B, int T, int H) {
-    const int lane = threadIdx.x & 63;
-    const long task = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const long task = static_cast<long>(blockIdx.x) * 32 + (threadIdx.x >> 3);
     const long total = static_cast<long>(B) * T * H;
-    if (task >= total) return;
-    const long row = task / H;
-    const int h = static_cast<int>(task % H);
-    const long at = row * H * kHd + h * kHd + lane;
-    float v = bf2f(out[at]) * bf2f(dout[at]);
-    v = wave_sum(v);
-    if (lane == 0) {
+    const int part = threadIdx.x & 7;
+    float v = 0.f;
+    long row = 0;
+    int h = 0;
+    if (task < total) {
+        row = task / H;
+        h = static_cast<int>(task % H);
+        const long at = row * H * kHd + h * kHd + part * 8;
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(out + at);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + at);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += bf2f(o[k]) * bf2f(d[k]);
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (task < total && part == 0) {
         const long b = row / T, t = row % T;
         delta[(b * H + h) * T + t] = v;
     }
@@ -448,7 +457,7 @@ int nf_attn_bwd(const void* qkv, const void* out, const float* lse, const void* 
     static const int attr2 = set_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel), kDqLds);
     if (attr1 || attr2) return -20;
     const long tasks = static_cast<long>(B) * T * H;
-    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(static_cast<unsigned>((tasks + 3) / 4)), dim3(256),
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(static_cast<unsigned>((tasks + 31) / 32)), dim3(256),
                        0, s, static_cast<const bf16*>(out), static_cast<const bf16*>(dout), delta,
                        B, T, H);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(T / 128, B * H), dim3(256), kDkvLds, s,

@@ -9,10 +9,12 @@
 //   nf_ln_fwd           optional residual add (x_out = x_in + delta) fused with
 //                       LayerNorm; one wave per row, the row lives in registers
 //   nf_ln_bwd           d(x) (+ incoming residual gradient) and per-workgroup
-//                       partial d(gamma), d(beta); nf_ln_bwd_reduce sums the partials
-//                       in a fixed order
+//                       partial d(gamma), d(beta) and column sums of d(x) (= bias
+//                       gradient of the projection feeding the residual stream); a
+//                       second launch sums the partials in a fixed order
 //   nf_gelu_fwd/bwd     tanh-GELU on the pre-activation (the bias comes from the GEMM
-//                       epilogue)
+//                       epilogue); nf_gelu_bwd_colsum also produces the bias gradient
+//                       of the layer in front of it
 //   nf_colsum           bias gradient: column sums of a [R, N] matrix, two fixed-order
 //                       stages
 //   nf_ce_fwd_bwd       softmax cross-entropy over a padded-stride logits matrix:
@@ -32,6 +34,21 @@ using namespace nfd;
 namespace {
 
 constexpr int kLnMaxChunks = 8;  // 64 lanes x 4 values x 8 chunks = 2048 columns
+
+constexpr float kGeluK = 0.7978845608028654f;  // sqrt(2/pi)
+constexpr float kGeluC = 0.044715f;
+
+__device__ __forceinline__ float tanh_fast(float u) {
+    // tanh(u) = 1 - 2 / (exp(2u) + 1); exact limits at +-inf
+    const float e = __expf(2.f * u);
+    return 1.f - 2.f / (e + 1.f);
+}
+
+__device__ __forceinline__ float gelu_grad(float v) {
+    const float t = tanh_fast(kGeluK * (v + kGeluC * v * v * v));
+    const float dt = (1.f - t * t) * kGeluK * (1.f + 3.f * kGeluC * v * v);
+    return 0.5f * (1.f + t) + 0.5f * v * dt;
+}
 
 __device__ __forceinline__ void load4(const bf16* p, float (&f)[4]) {
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
@@ -163,21 +180,23 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf1
 }
 
 // Workgroup b owns rows [b*rpb, (b+1)*rpb); wave w takes every 4th of them.
-// partial[b][0][c] = sum dy*xhat, partial[b][1][c] = sum dy over the block's rows.
+// partial[b][0][c] = sum dy*xhat, partial[b][1][c] = sum dy, partial[b][2][c] =
+// sum dx over the block's rows (dx is the gradient of the residual stream, so
+// its column sums are the bias gradient of the projection that wrote into it).
 template <bool kHasRes>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16* dy, const bf16* x,
                                                      const bf16* gamma, const float* mean,
                                                      const float* rstd, const bf16* dres,
                                                      bf16* dx, float* partial, int R, int C,
                                                      int rpb) {
-    extern __shared__ float red[];  // [4 waves][2][C]
+    extern __shared__ float red[];  // [4 waves][3][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[kLnMaxChunks][4], db[kLnMaxChunks][4], g[kLnMaxChunks][4];
+    float dg[kLnMaxChunks][4], db[kLnMaxChunks][4], ds[kLnMaxChunks][4], g[kLnMaxChunks][4];
 #pragma unroll
     for (int ch = 0; ch < kLnMaxChunks; ++ch) {
         const int c0 = ch * 256 + lane * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dg[ch][i] = 0.f; db[ch][i] = 0.f; g[ch][i] = 0.f; }
+        for (int i = 0; i < 4; ++i) { dg[ch][i] = 0.f; db[ch][i] = 0.f; ds[ch][i] = 0.f; g[ch][i] = 0.f; }
         if (c0 < C) load4(gamma + c0, g[ch]);
     }
     const int row_end = min(R, (static_cast<int>(blockIdx.x) + 1) * rpb);
@@ -218,11 +237,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16* dy, const bf16*
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] += r[i];
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ds[ch][i] += o[i];
                 store4(dx + base + c0, o);
             }
         }
     }
-    float* mine = red + wave * 2 * C;
+    float* mine = red + wave * 3 * C;
 #pragma unroll
     for (int ch = 0; ch < kLnMaxChunks; ++ch) {
         const int c0 = ch * 256 + lane * 4;
@@ -231,41 +252,43 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16* dy, const bf16*
             for (int i = 0; i < 4; ++i) {
                 mine[c0 + i] = dg[ch][i];
                 mine[C + c0 + i] = db[ch][i];
+                mine[2 * C + c0 + i] = ds[ch][i];
             }
         }
     }
     __syncthreads();
-    float* out = partial + static_cast<long>(blockIdx.x) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256)
-        out[i] = (red[i] + red[2 * C + i]) + (red[4 * C + i] + red[6 * C + i]);
+    float* out = partial + static_cast<long>(blockIdx.x) * 3 * C;
+    for (int i = threadIdx.x; i < 3 * C; i += 256)
+        out[i] = (red[i] + red[3 * C + i]) + (red[6 * C + i] + red[9 * C + i]);
 }
 
+// 64 columns per workgroup; wave w sums a quarter of the partial rows.
 __global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* partial, bf16* dgamma,
-                                                            bf16* dbeta, int nblocks, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+                                                            bf16* dbeta, bf16* dxsum, int nblocks,
+                                                            int C) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 1 < nblocks; b += 2) {
-        s0 += partial[static_cast<long>(b) * 2 * C + i];
-        s1 += partial[static_cast<long>(b + 1) * 2 * C + i];
+    if (i < 3 * C) {
+        const int lo = (nblocks * wave) >> 2, hi = (nblocks * (wave + 1)) >> 2;
+        int b = lo;
+        for (; b + 1 < hi; b += 2) {
+            s0 += partial[static_cast<long>(b) * 3 * C + i];
+            s1 += partial[static_cast<long>(b + 1) * 3 * C + i];
+        }
+        if (b < hi) s0 += partial[static_cast<long>(b) * 3 * C + i];
     }
-    if (b < nblocks) s0 += partial[static_cast<long>(b) * 2 * C + i];
-    const bf16 r = f2bf(s0 + s1);
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave != 0 || i >= 3 * C) return;
+    const bf16 r = f2bf((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
     if (i < C) dgamma[i] = r;
-    else dbeta[i - C] = r;
+    else if (i < 2 * C) dbeta[i - C] = r;
+    else if (dxsum != nullptr) dxsum[i - 2 * C] = r;
 }
 
 // ---------------------------------------------------------------------------
-constexpr float kGeluK = 0.7978845608028654f;  // sqrt(2/pi)
-constexpr float kGeluC = 0.044715f;
-
-__device__ __forceinline__ float tanh_fast(float u) {
-    // tanh(u) = 1 - 2 / (exp(2u) + 1); exact limits at +-inf
-    const float e = __expf(2.f * u);
-    return 1.f - 2.f / (e + 1.f);
-}
-
 __global__ void __launch_bounds__(256) gelu_fwd_kernel(const bf16* x, bf16* y, long n8) {
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
          i += static_cast<long>(gridDim.x) * 256) {
@@ -290,18 +313,16 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const bf16* x, const bf16
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float v = bf2f(a[k]);
-            const float t = tanh_fast(kGeluK * (v + kGeluC * v * v * v));
-            const float dt = (1.f - t * t) * kGeluK * (1.f + 3.f * kGeluC * v * v);
-            o[k] = f2bf(bf2f(d[k]) * (0.5f * (1.f + t) + 0.5f * v * dt));
+            o[k] = f2bf(bf2f(d[k]) * gelu_grad(bf2f(a[k])));
         }
         reinterpret_cast<bf16x8*>(dx)[i] = o;
     }
 }
 
 // ---------------------------------------------------------------------------
-// Column sums.  Workgroup (cx, chunk): columns [128*cx, 128*cx+128), rows of the
-// chunk; a lane owns two adjacent columns, wave w takes every 4th row.
+// Column sums.  Narrow variant (any even N): workgroup (cx, chunk) = columns
+// [128*cx, 128*cx+128), rows of the chunk; a lane owns two adjacent columns,
+// wave w takes every 4th row.
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const bf16* m, float* partial, int R,
                                                              int N, long ld, int rows_per_chunk) {
     __shared__ float red[4][128];
@@ -329,13 +350,66 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const bf16* m, floa
     }
 }
 
+// Wide variant (N and ld multiples of 8, 16-byte aligned rows): a lane owns 8
+// adjacent columns, a wave 512.  kGelu: the matrix is d(act); every element is
+// first turned into d(pre-activation) with the tanh-GELU derivative at x and
+// written to dx, and the sums are taken of that.
+template <bool kGelu>
+__global__ void __launch_bounds__(256) colsum8_partial_kernel(const bf16* m, const bf16* x,
+                                                              bf16* dx, float* partial, int R,
+                                                              int N, long ld, int rows_per_chunk) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + lane * 8;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(R, r0 + rows_per_chunk);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+#pragma unroll 4
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const long at = static_cast<long>(r) * ld + c;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(m + at);
+            if (kGelu) {
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + at);
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    o[k] = f2bf(bf2f(v[k]) * gelu_grad(bf2f(xv[k])));
+                    acc[k] += bf2f(o[k]);
+                }
+                *reinterpret_cast<bf16x8*>(dx + at) = o;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = acc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int col = blockIdx.x * 512 + i;
+        if (col < N)
+            partial[static_cast<long>(blockIdx.y) * N + col] =
+                (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+
+// 64 columns per workgroup; wave w sums a quarter of the chunks.
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* partial, bf16* out,
                                                            int chunks, int N) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= N) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[static_cast<long>(k) * N + col];
-    out[col] = f2bf(s);
+    if (col < N) {
+        const int lo = (chunks * wave) >> 2, hi = (chunks * (wave + 1)) >> 2;
+        for (int k = lo; k < hi; ++k) s += partial[static_cast<long>(k) * N + col];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < N)
+        out[col] = f2bf((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // ---------------------------------------------------------------------------
@@ -505,17 +579,24 @@ int nf_ln_bwd_blocks(int R) {
     return b < 256 ? b : 256;
 }
 
-// partial: nf_ln_bwd_blocks(R) * 2 * C floats of workspace.  dres may be null;
-// dx may alias dres or dy.
+// partial: nf_ln_bwd_blocks(R) * 3 * C floats of workspace.  dres may be null;
+// dx may alias dres or dy.  dxsum (may be null) receives the column sums of dx.
 int nf_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
               const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
-              float* partial, int R, int C, hipStream_t s) {
+              void* dxsum, float* partial, int R, int C, hipStream_t s) {
     if (R <= 0 || C <= 0 || C % 4 != 0 || C > kLnMaxChunks * 256) return -1;
     if (!aligned(dy, 8) || !aligned(x, 8) || !aligned(dx, 8) || !aligned(gamma, 8)) return -2;
     if (dres != nullptr && !aligned(dres, 8)) return -2;
     const int nb = nf_ln_bwd_blocks(R);
     const int rpb = (R + nb - 1) / nb;
-    const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
+    const size_t lds = static_cast<size_t>(12) * C * sizeof(float);
+    static const hipError_t a1 = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(ln_bwd_kernel<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 12 * kLnMaxChunks * 256 * 4);
+    static const hipError_t a2 = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(ln_bwd_kernel<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 12 * kLnMaxChunks * 256 * 4);
+    if (a1 != hipSuccess || a2 != hipSuccess) return -20;
     if (dres != nullptr)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nb), dim3(256), lds, s,
                            static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
@@ -527,8 +608,9 @@ int nf_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mea
                            static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
                            static_cast<const bf16*>(gamma), mean, rstd, nullptr,
                            static_cast<bf16*>(dx), partial, R, C, rpb);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, partial,
-                       static_cast<bf16*>(dgamma), static_cast<bf16*>(dbeta), nb, C);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * C + 63) / 64), dim3(256), 0, s, partial,
+                       static_cast<bf16*>(dgamma), static_cast<bf16*>(dbeta),
+                       static_cast<bf16*>(dxsum), nb, C);
     return NF_NN_OK();
 }
 
@@ -547,17 +629,38 @@ int nf_gelu_bwd(const void* x, const void* dy, void* dx, long n, hipStream_t s) 
     return NF_NN_OK();
 }
 
-int nf_colsum_chunks() { return 32; }
+int nf_colsum_chunks() { return 64; }
 
 // out[c] = sum_r m[r][c]; partial: nf_colsum_chunks() * N floats of workspace.
 int nf_colsum(const void* m, void* out, float* partial, int R, int N, long ld, hipStream_t s) {
     if (R <= 0 || N <= 0 || N % 2 != 0 || ld % 2 != 0 || ld < N || !aligned(m, 4)) return -1;
     const int chunks = nf_colsum_chunks();
     const int rows = (R + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 127) / 128, chunks), dim3(256), 0, s,
-                       static_cast<const bf16*>(m), partial, R, N, ld, rows);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial,
+    if (N % 8 == 0 && ld % 8 == 0 && aligned(m, 16))
+        hipLaunchKernelGGL(colsum8_partial_kernel<false>, dim3((N + 511) / 512, chunks), dim3(256),
+                           0, s, static_cast<const bf16*>(m), nullptr, nullptr, partial, R, N, ld,
+                           rows);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 127) / 128, chunks), dim3(256), 0, s,
+                           static_cast<const bf16*>(m), partial, R, N, ld, rows);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, partial,
                        static_cast<bf16*>(out), chunks, N);
+    return NF_NN_OK();
+}
+
+// dx = dy * gelu'(x) for contiguous [R][N] matrices (dx may alias dy) and
+// dbias[c] = sum_r dx[r][c], in one pass.
+int nf_gelu_bwd_colsum(const void* x, const void* dy, void* dx, void* dbias, float* partial, int R,
+                       int N, hipStream_t s) {
+    if (R <= 0 || N <= 0 || N % 8 != 0 || !aligned(x, 16) || !aligned(dy, 16) || !aligned(dx, 16))
+        return -1;
+    const int chunks = nf_colsum_chunks();
+    const int rows = (R + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum8_partial_kernel<true>, dim3((N + 511) / 512, chunks), dim3(256), 0, s,
+                       static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
+                       static_cast<bf16*>(dx), partial, R, N, static_cast<long>(N), rows);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, partial,
+                       static_cast<bf16*>(dbias), chunks, N);
     return NF_NN_OK();
 }
 

@@ -163,23 +163,23 @@ class GPT2NativeTrainer(GroupTrainer):
         torch.mm(dlog.t(), b.lnf, out=g["wte.weight"])  # LM head shares the embedding matrix
         torch.mm(dlog, w["wte.weight"], out=b.dln)
         stf = b.stats[2 * L]
+        # every LayerNorm backward also sums its d(x) over the rows: that is the bias
+        # gradient of the projection that wrote into the residual stream before it
         nn_ops.ln_bwd(b.dln, b.x[L], w["ln_f.weight"], stf[0], stf[1], b.dres,
-                      g["ln_f.weight"], g["ln_f.bias"])
+                      g["ln_f.weight"], g["ln_f.bias"], dxsum=g[f"h.{L - 1}.c_proj.bias"])
         for l in reversed(range(L)):
             p = f"h.{l}."
             st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
             # MLP: x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
-            nn_ops.colsum(b.dres, g[p + "c_proj.bias"])
             torch.mm(b.dres.t(), b.act[l], out=g[p + "c_proj.weight"])
             torch.mm(b.dres, w[p + "c_proj.weight"], out=b.dact)
-            nn_ops.gelu_bwd(b.fc[l], b.dact, b.dact)
-            nn_ops.colsum(b.dact, g[p + "c_fc.bias"])
+            nn_ops.gelu_bwd_colsum(b.fc[l], b.dact, b.dact, g[p + "c_fc.bias"])
             torch.mm(b.dact.t(), b.ln2[l], out=g[p + "c_fc.weight"])
             torch.mm(b.dact, w[p + "c_fc.weight"], out=b.dln)
             nn_ops.ln_bwd(b.dln, b.x_mid[l], w[p + "ln_2.weight"], st2[0], st2[1], b.dres,
-                          g[p + "ln_2.weight"], g[p + "ln_2.bias"], dres=b.dres)
+                          g[p + "ln_2.weight"], g[p + "ln_2.bias"], dres=b.dres,
+                          dxsum=g[p + "attn.c_proj.bias"])
             # attention: x_mid = x + c_proj(attn(c_attn(ln_1(x))))
-            nn_ops.colsum(b.dres, g[p + "attn.c_proj.bias"])
             torch.mm(b.dres.t(), b.att[l], out=g[p + "attn.c_proj.weight"])
             torch.mm(b.dres, w[p + "attn.c_proj.weight"], out=b.datt)
             attn_ops.causal_attention_bwd(b.qkv[l], b.att[l], b.lse[l], b.datt, b.dqkv,
@@ -188,7 +188,8 @@ class GPT2NativeTrainer(GroupTrainer):
             torch.mm(b.dqkv.t(), b.ln1[l], out=g[p + "attn.c_attn.weight"])
             torch.mm(b.dqkv, w[p + "attn.c_attn.weight"], out=b.dln)
             nn_ops.ln_bwd(b.dln, b.x[l], w[p + "ln_1.weight"], st1[0], st1[1], b.dres,
-                          g[p + "ln_1.weight"], g[p + "ln_1.bias"], dres=b.dres)
+                          g[p + "ln_1.weight"], g[p + "ln_1.bias"], dres=b.dres,
+                          dxsum=g[f"h.{l - 1}.c_proj.bias"] if l > 0 else None)
         nn_ops.embed_bwd(tokens[:, :-1].contiguous(), b.dres, g["wte.weight"], g["wpe.weight"],
                          b.batch, b.seq)
 

@@ -27,7 +27,8 @@ _SIGS = {
     "nf_embed_bwd": ([P, P, P, P, P, I, I, I, P], I),
     "nf_ln_fwd": ([P, P, P, P, P, P, P, P, I, I, FL, P], I),
     "nf_ln_bwd_blocks": ([I], I),
-    "nf_ln_bwd": ([P, P, P, P, P, P, P, P, P, P, I, I, P], I),
+    "nf_ln_bwd": ([P, P, P, P, P, P, P, P, P, P, P, I, I, P], I),
+    "nf_gelu_bwd_colsum": ([P, P, P, P, P, I, I, P], I),
     "nf_gelu_fwd": ([P, P, L, P], I),
     "nf_gelu_bwd": ([P, P, P, L, P], I),
     "nf_colsum_chunks": ([], I),
@@ -148,14 +149,15 @@ def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Te
 
 def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
            rstd: torch.Tensor, dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
-           dres: torch.Tensor | None = None) -> None:
-    """``dx = LayerNorm'(dy) (+ dres)``, ``dgamma``, ``dbeta`` (bf16, overwritten)."""
+           dres: torch.Tensor | None = None, dxsum: torch.Tensor | None = None) -> None:
+    """``dx = LayerNorm'(dy) (+ dres)``, ``dgamma``, ``dbeta`` (bf16, overwritten);
+    ``dxsum`` (optional) receives the column sums of ``dx``."""
     R, C = x.shape
     if _gpu(x):
         nb = int(_fn("nf_ln_bwd_blocks")(R))
-        ws = _workspace(x.device, nb * 2 * C)
+        ws = _workspace(x.device, nb * 3 * C)
         library.check(_fn("nf_ln_bwd")(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres),
-                                       _p(dx), _p(dgamma), _p(dbeta), _p(ws), R, C,
+                                       _p(dx), _p(dgamma), _p(dbeta), _p(dxsum), _p(ws), R, C,
                                        library.stream_ptr(x.device)), "ln_bwd")
         return
     xh = (x.float() - mean[:, None]) * rstd[:, None]
@@ -168,6 +170,8 @@ def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.T
         out = out + dres.float()
     dgamma.copy_((d * xh).sum(0).to(torch.bfloat16))
     dbeta.copy_(d.sum(0).to(torch.bfloat16))
+    if dxsum is not None:
+        dxsum.copy_(out.sum(0).to(torch.bfloat16))
     dx.copy_(out.to(torch.bfloat16))
 
 
@@ -190,6 +194,23 @@ def gelu_bwd(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor) -> None:
         t = torch.tanh(k * (v + c * v**3))
         dt = (1 - t * t) * k * (1 + 3 * c * v * v)
         dx.copy_((dy.float() * (0.5 * (1 + t) + 0.5 * v * dt)).to(torch.bfloat16))
+
+
+def gelu_bwd_colsum(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor,
+                    dbias: torch.Tensor) -> None:
+    """``dx = dy * gelu'(x)`` and ``dbias = column sums of dx`` in one pass over
+    contiguous ``[R, N]`` matrices."""
+    R, N = x.shape
+    if _gpu(x):
+        _need(x, torch.bfloat16, "x")
+        _need(dy, torch.bfloat16, "dy")
+        chunks = int(_fn("nf_colsum_chunks")())
+        ws = _workspace(x.device, chunks * N)
+        library.check(_fn("nf_gelu_bwd_colsum")(_p(x), _p(dy), _p(dx), _p(dbias), _p(ws), R, N,
+                                                library.stream_ptr(x.device)), "gelu_bwd_colsum")
+    else:
+        gelu_bwd(x, dy, dx)
+        dbias.copy_(dx.float().sum(0).to(torch.bfloat16))
 
 
 def colsum(m: torch.Tensor, out: torch.Tensor) -> None:

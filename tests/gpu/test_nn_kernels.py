@@ -35,13 +35,14 @@ def test_layernorm(R, C):
         nn_ops.ln_fwd(xo, t[2], t[3], y2, m2, r2)
         dx, dg, db = (torch.empty(R, C, dtype=BF, device=dev), torch.empty(C, dtype=BF, device=dev),
                       torch.empty(C, dtype=BF, device=dev))
-        nn_ops.ln_bwd(t[4], xo, t[2], mean, rstd, dx, dg, db, dres=t[5])
+        dxs = torch.empty(C, dtype=BF, device=dev)
+        nn_ops.ln_bwd(t[4], xo, t[2], mean, rstd, dx, dg, db, dres=t[5], dxsum=dxs)
         dx2 = torch.empty_like(dx)
         nn_ops.ln_bwd(t[4], xo, t[2], mean, rstd, dx2, dg, db)
-        outs[dev] = [v.float().cpu() for v in (xo, y, y2, mean, rstd, dx, dx2, dg, db)]
-    names = ["x_out", "y", "y_nodelta", "mean", "rstd", "dx_res", "dx", "dgamma", "dbeta"]
+        outs[dev] = [v.float().cpu() for v in (xo, y, y2, mean, rstd, dx, dx2, dg, db, dxs)]
+    names = ["x_out", "y", "y_nodelta", "mean", "rstd", "dx_res", "dx", "dgamma", "dbeta", "dxsum"]
     for name, a, b_ in zip(names, outs["cpu"], outs[DEV]):
-        tol = dict(rtol=2e-2, atol=2e-2) if name not in ("dgamma", "dbeta") else dict(
+        tol = dict(rtol=2e-2, atol=2e-2) if name not in ("dgamma", "dbeta", "dxsum") else dict(
             rtol=2e-2, atol=2e-2 * max(1.0, R**0.5 / 4))
         torch.testing.assert_close(b_, a, **tol, msg=lambda m, n=name: f"{n}: {m}")
     assert torch.equal(outs["cpu"][0], outs[DEV][0])  # residual add rounds identically
@@ -59,7 +60,12 @@ def test_gelu_colsum_sgd():
     ref.backward(dy.float())
     torch.testing.assert_close(y.float().cpu(), ref.detach(), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(dx.float().cpu(), leaf.grad, rtol=2e-2, atol=2e-2)
-    # in-place backward (dx aliases dy), as the trainer uses it
+    # fused with the bias gradient, in place (dx aliases dy), as the trainer uses it
+    dbias = torch.empty(N, dtype=BF, device=DEV)
+    dy2 = dyd.clone()
+    nn_ops.gelu_bwd_colsum(xd, dy2, dy2, dbias)
+    assert torch.equal(dy2, dx)
+    torch.testing.assert_close(dbias.float(), dx.float().sum(0), rtol=1e-2, atol=0.5)
     nn_ops.gelu_bwd(xd, dyd, dyd)
     assert torch.equal(dyd, dx)
     for rows, cols, ld in ((4096, 768, 768), (4096, 2304, 2304), (100, 50, 64), (4092, 50257 - 1, 50304)):
