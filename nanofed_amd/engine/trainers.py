@@ -89,13 +89,64 @@ class TorchGroupTrainer(GroupTrainer):
         self._acc = torch.zeros(len(pool), 3, dtype=torch.float32, device=self.device)
         self._amp = cfg.dtype == "bf16" and self.device.type == "cuda"
         self._dp_step = 0
+        # whole-step hipGraphs (forward + backward + SGD of one client): DP draws
+        # its noise offset on the host, so it stays eager
+        self._use_graph = (
+            cfg.graph_capture and self.device.type == "cuda" and cfg.dp is None
+        )
+        self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, torch.Tensor]] = {}
+        self._channels_last = self.device.type == "cuda" and shards.kind == "image"
 
     # -- one optimisation step of client k --------------------------------
     def _step(self, k: int, rows: torch.Tensor) -> None:
+        """Full batches replay the client's captured step; the ragged last
+        batch of an epoch runs eagerly."""
+        if self._use_graph and rows.numel() == self.cfg.batch_size:
+            graph, static_rows = self._graph_for(k)
+            static_rows.copy_(rows)
+            graph.replay()
+        else:
+            self._eager_step(k, rows)
+
+    def _graph_for(self, k: int) -> tuple[torch.cuda.CUDAGraph, torch.Tensor]:
+        """Capture client k's optimisation step once.  The warm-up iterations
+        (library autotuning, lazy allocations) really train, so the client's
+        parameters, float buffers and counters are restored afterwards."""
+        if k in self._graphs:
+            return self._graphs[k]
+        arena = self.pool[k]
+        keep = arena.data.clone()
+        keep_acc = self._acc[k].clone()
+        int_bufs = [b.clone() for b in self.modules[k].buffers() if not b.dtype.is_floating_point]
+        static_rows = (
+            torch.arange(self.cfg.batch_size, device=self.device) + int(self.shards.offsets[k])
+        )
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._eager_step(k, static_rows)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._eager_step(k, static_rows)
+        arena.data.copy_(keep)
+        if arena.grad is not None:
+            arena.grad.zero_()
+        self._acc[k].copy_(keep_acc)
+        live = [b for b in self.modules[k].buffers() if not b.dtype.is_floating_point]
+        for b, saved in zip(live, int_bufs):
+            b.copy_(saved)
+        self._graphs[k] = (graph, static_rows)
+        return self._graphs[k]
+
+    def _eager_step(self, k: int, rows: torch.Tensor) -> None:
         cfg = self.cfg
         module = self.modules[k]
         arena = self.pool[k]
         x, y = self.shards.batch(rows)
+        if self._channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self._amp):
             out = module(x)
             loss = classification_loss(out, y)
