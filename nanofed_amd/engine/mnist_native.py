@@ -305,6 +305,13 @@ class MnistCnnNativeTrainer(GroupTrainer):
         self.buf.nvalid.copy_(nvalid)
         self.metrics = torch.zeros(G, METRIC_COLUMNS, dtype=torch.float32, device=self.device)
         self._graph: torch.cuda.CUDAGraph | None = None
+        # staging table and (default-priority) side stream for the epoch shuffles
+        self._idx_stage = torch.empty_like(self.buf.idx)
+        self._idx_stream = torch.cuda.Stream(self.device) if cfg.graph_capture else None
+        self._idx_ready = torch.cuda.Event()
+        self._idx_consumed = torch.cuda.Event()
+        self._idx_consumed.record(torch.cuda.current_stream(self.device))
+        self._idx_key: tuple[int, int] | None = None
         self._eval: NativeBuffers | None = None
         self._eval_data = (data.eval_inputs, data.eval_labels, mean, std)
         self._sizes = torch.tensor(
@@ -312,15 +319,39 @@ class MnistCnnNativeTrainer(GroupTrainer):
         )
 
     # -- batches ----------------------------------------------------------
-    def _fill_indices(self, round_idx: int, epoch: int) -> None:
-        B = BATCH
+    def _fill_indices(self, round_idx: int, epoch: int, into: torch.Tensor | None = None) -> None:
+        target = self.buf.idx if into is None else into
         for k in range(len(self.pool)):
             perm = self.shards.epoch_permutation(k, round_idx, epoch).to(torch.int32)
-            row = self.buf.idx[k]
+            row = target[k]
             n = perm.numel()
             row[:n] = perm
             if n < row.numel():
                 row[n:] = perm[0]
+
+    # The shuffles of an epoch are a few dozen tiny launches per client.  They are
+    # issued on a second stream while the previous epoch's graph is running and
+    # land in a staging table; the training stream only pays for one copy.
+    def _prefetch_indices(self, round_idx: int, epoch: int) -> None:
+        if self._idx_stream is None:
+            return
+        self._idx_stream.wait_event(self._idx_consumed)
+        with torch.cuda.stream(self._idx_stream):
+            self._fill_indices(round_idx, epoch, into=self._idx_stage)
+            self._idx_ready.record()
+        self._idx_key = (round_idx, epoch)
+
+    def _take_indices(self, round_idx: int, epoch: int) -> None:
+        if self._idx_stream is None:
+            self._fill_indices(round_idx, epoch)
+            return
+        if self._idx_key != (round_idx, epoch):
+            self._prefetch_indices(round_idx, epoch)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(self._idx_ready)
+        self.buf.idx.copy_(self._idx_stage)
+        self._idx_consumed.record(main)
+        self._idx_key = None
 
     def _ensure_graph(self, round_idx: int) -> None:
         """Record one local epoch (every step of every client) in a hipGraph.
@@ -352,9 +383,11 @@ class MnistCnnNativeTrainer(GroupTrainer):
         self._ensure_graph(round_idx)
         self.buf.pack()
         for epoch in range(cfg.local_epochs):
-            self._fill_indices(round_idx, epoch)
+            self._take_indices(round_idx, epoch)
             self.buf.metrics.zero_()
             self._run_epoch()
+            nxt = (round_idx, epoch + 1) if epoch + 1 < cfg.local_epochs else (round_idx + 1, 0)
+            self._prefetch_indices(*nxt)
         m = self.buf.metrics
         batches = m[:, 2].clamp(min=1.0)
         out = self.metrics
