@@ -139,7 +139,12 @@ if __name__ == "__main__":
     ap.add_argument("--clients", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true", help="keep the INFO/DEBUG log lines")
     a = ap.parse_args()
+    if not a.verbose:
+        from nanofed_amd.utils import LogConfig, Logger, LogLevel
+
+        Logger().configure(LogConfig(level=LogLevel.WARNING))
     res = run_mlp_http(a) if a.config == "mlp_http" else run_engine(a.config, a)
     if res:
         print(json.dumps(res), flush=True)

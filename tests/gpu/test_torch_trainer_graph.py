@@ -10,12 +10,12 @@ from nanofed_amd.parallel import Communicator
 pytestmark = pytest.mark.gpu
 
 
-def _run(graph: bool, **kw):
+def _run(graph: bool, rounds: int = 3, **kw):
     torch.cuda.set_device(0)
     cfg = EngineConfig(backend="torch", graph_capture=graph, num_clients=2, local_epochs=1,
                        batch_size=32, seed=3, **kw)
     eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
-    reps = eng.run(3)
+    reps = eng.run(rounds)
     return eng.global_arena.data.float().cpu(), [r.agg_metrics["loss"] for r in reps], eng
 
 
@@ -33,12 +33,15 @@ def test_resnet_bf16_graph_tracks_eager_and_learns():
     # 150 samples: four full batches replay the graph, the ragged fifth runs eagerly
     kw = dict(model="resnet18", dataset="synthetic_cifar10", samples_per_client=150,
               eval_samples=64, learning_rate=0.05)
-    a, la, _ = _run(False, **kw)
-    b, lb, eng = _run(True, **kw)
+    # bf16 convolutions may pick different algorithms between runs and SGD amplifies
+    # the difference round by round: compare one round (8 replays + 2 eager steps)
+    # loosely, then check that the graph-captured run keeps learning
+    a, la, _ = _run(False, rounds=1, **kw)
+    b, lb, eng = _run(True, rounds=1, **kw)
     assert len(eng.trainer._graphs) == 2
-    assert all(torch.isfinite(torch.tensor(lb)))
-    # bf16 convolutions may pick different algorithms between runs: compare loosely
-    assert lb == pytest.approx(la, rel=0.15)
+    assert lb == pytest.approx(la, rel=0.1)
     rel = float((a - b).norm() / a.norm())
     assert rel < 0.05, rel
-    assert lb[-1] < lb[0]
+    _, losses, _ = _run(True, rounds=4, **kw)
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]
