@@ -135,29 +135,34 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16* qkv, bf16* ou
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s = mfma32(row_frag(Ks, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), qf[ks], s);
+            // raw scores; the 1/sqrt(d) * log2(e) factor is folded into the exponent
             const bool diag = key0 + 31 > q0;
             float mx = kNegBig;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = s[r] * sc2;
-                if (diag && key0 + acc_row(r, lane) > q0 + n) v = kNegBig;
-                s[r] = v;
-                mx = fmaxf(mx, v);
+                if (diag && key0 + acc_row(r, lane) > q0 + n) s[r] = kNegBig;
+                mx = fmaxf(mx, s[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - mn);
-            m = mn;
+            // the running maximum rarely moves after the first tiles: rescale the
+            // accumulators only when some query of the wave needs it
+            if (__any(mx > m)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2((m - mn) * sc2);
+                m = mn;
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
+            const float msc = m * sc2;
             float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(s[r] - mn);
+                const float p = fast_exp2(fmaf(s[r], sc2, -msc));
                 s[r] = p;
                 rs += p;
             }
-            l = l * alpha + rs;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            l += rs;
             const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
             o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 0, lane), p0, o0);
             o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 32, lane), p0, o1);
@@ -185,7 +190,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16* qkv, bf16* ou
         *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hh) = c;
     }
     if (hh == 0)
-        lse[(static_cast<long>(blockIdx.y)) * T + q0 + n] = m / kLog2e + __logf(l);
+        lse[(static_cast<long>(blockIdx.y)) * T + q0 + n] = m * kScale + __logf(l);
 }
 
 // ---------------------------------------------------------------------------
