@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from nanofed_amd.engine import EngineConfig, FederatedEngine  # noqa: E402
+from nanofed_amd.engine import DPConfig, EngineConfig, FederatedEngine  # noqa: E402
 from nanofed_amd.engine.mnist_native import STAGES  # noqa: E402
 from nanofed_amd.parallel import Communicator  # noqa: E402
 
@@ -24,12 +24,14 @@ def main() -> None:
     ap.add_argument("--clients", type=int, default=8)
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--only", default="", help="comma-separated stage names")
+    ap.add_argument("--dp", action="store_true", help="per-sample DP-SGD step (two backward passes)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     comm = Communicator(device=torch.device("cuda", 0))
     cfg = EngineConfig(model="mnist_cnn", num_clients=args.clients, samples_per_client=640,
                        batch_size=64, local_epochs=1, eval_samples=64, backend="native",
-                       graph_capture=False)
+                       graph_capture=False,
+                       dp=DPConfig(max_gradient_norm=1.0, noise_multiplier=1.1) if args.dp else None)
     eng = FederatedEngine(cfg, comm=comm)
     tr = eng.trainer
     buf = tr.buf
@@ -38,7 +40,8 @@ def main() -> None:
     buf.train_steps(0, 2)  # realistic activations / gradients in every buffer
     torch.cuda.synchronize()
     out = {}
-    order = [n for n in STAGES if n not in ("pack", "dp_scale")]
+    skip = ("pack", "finalize_sgd") if args.dp else ("pack", "dp_scale")
+    order = [n for n in STAGES if n not in skip]
     if args.only:
         order = args.only.split(",")
     per_graph = 25
