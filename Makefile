@@ -35,7 +35,7 @@ clean:
 	find . -name __pycache__ -type d -prune -exec rm -rf {} +
 
 docs:
-	@command -v mkdocs >/dev/null && mkdocs build || echo "mkdocs not installed: documentation lives in docs/*.md, DESIGN.md and README.md"
+	@command -v mkdocs >/dev/null && mkdocs build || echo "mkdocs not installed: the documentation sources are the Markdown files under docs/"
 
 changelog:
 	python scripts/changelog.py
