@@ -139,6 +139,10 @@ class FederatedEngine:
             self.layout = make_layout(self._host_model)
         else:
             self.layout = ArenaLayout.from_module(self._host_model)
+            if self.device.type == "cuda":
+                # convolution weights live in NHWC order on the GPU (no-op for
+                # models without 4-D parameters)
+                self.layout = self.layout.with_channels_last()
         self.global_arena = ParameterArena(self.layout, self.device)
         self.global_arena.load_state_dict(self._host_model.state_dict())
         self.comm.broadcast(self.global_arena.data, src=0)

@@ -53,12 +53,16 @@ class ArenaLayout:
     """Immutable key -> segment table shared by every arena of one model."""
 
     def __init__(
-        self, segments: list[Segment], perms: dict[str, torch.Tensor] | None = None
+        self, segments: list[Segment], perms: dict[str, torch.Tensor] | None = None,
+        view_strides: dict[str, tuple[int, ...]] | None = None,
     ) -> None:
         self.segments = tuple(segments)
         # storage permutations: stored_flat = canonical_flat[perm] for the
         # tensors a kernel family wants in its own element order
         self.perms = dict(perms or {})
+        # permutations that are plain dimension reorderings can still be viewed as
+        # ordinary (strided) tensors of the canonical shape: name -> strides
+        self.view_strides = dict(view_strides or {})
         self.inv_perms = {k: torch.argsort(v) for k, v in self.perms.items()}
         self._by_name = {s.name: s for s in segments}
         if len(self._by_name) != len(segments):
@@ -115,6 +119,32 @@ class ArenaLayout:
                 raise DeviceError(f"permutation of {name} has the wrong length")
         return ArenaLayout(list(self.segments), perms)
 
+    def with_channels_last(self) -> "ArenaLayout":
+        """Store every trainable 4-D tensor (convolution weights ``[O, I, H, W]``)
+        in ``[O, H, W, I]`` order.  Such a tensor is viewed with channels-last
+        strides, so a bound module sees the usual shape while the convolution
+        library gets NHWC weights without a transposition per call."""
+        perms, strides = dict(self.perms), dict(self.view_strides)
+        for s in self.segments:
+            if s.trainable and len(s.shape) == 4 and s.name not in perms:
+                o, i, h, w = s.shape
+                idx = torch.arange(s.numel).view(o, i, h, w)
+                perms[s.name] = idx.permute(0, 2, 3, 1).reshape(-1)
+                strides[s.name] = (h * w * i, 1, w * i, i)
+        return ArenaLayout(list(self.segments), perms, strides)
+
+    def bindable(self) -> bool:
+        """True when every permuted tensor still has a strided view."""
+        return all(name in self.view_strides for name in self.perms)
+
+    def view_of(self, flat: torch.Tensor, seg: Segment) -> torch.Tensor:
+        """The tensor of ``seg`` inside ``flat``: canonical shape, and canonical
+        VALUES whenever the storage order is expressible as strides."""
+        strides = self.view_strides.get(seg.name)
+        if strides is not None:
+            return torch.as_strided(flat, seg.shape, strides, flat.storage_offset() + seg.offset)
+        return flat[seg.offset : seg.offset + seg.numel].view(seg.shape)
+
 
 class ArenaStateDict(dict):
     """``state_dict``-shaped dictionary whose values are views into one flat
@@ -124,10 +154,7 @@ class ArenaStateDict(dict):
     def __init__(self, layout: ArenaLayout, flat: torch.Tensor) -> None:
         if flat.dim() != 1 or flat.numel() != layout.numel:
             raise DeviceError("flat buffer does not match the arena layout")
-        super().__init__(
-            (s.name, flat[s.offset : s.offset + s.numel].view(s.shape))
-            for s in layout.segments
-        )
+        super().__init__((s.name, layout.view_of(flat, s)) for s in layout.segments)
         self.layout = layout
         self.flat = flat
 
@@ -205,7 +232,7 @@ class ParameterArena:
         if self.grad is None:
             raise DeviceError("arena has no gradient buffer")
         return {
-            s.name: self.grad[s.offset : s.offset + s.numel].view(s.shape)
+            s.name: self.layout.view_of(self.grad, s)
             for s in self.layout.segments
             if s.trainable
         }
@@ -250,7 +277,7 @@ class ParameterArena:
         """Re-point ``module``'s parameters, gradients and float buffers at
         the arena, so autograd and the arena kernels operate on the same
         memory.  Integer buffers keep their own storage (``sync_buffers``)."""
-        if self.layout.perms:
+        if not self.layout.bindable():
             raise DeviceError(
                 "an arena with permuted storage cannot back a torch module; "
                 "use state_dict()/load_state_dict() at the boundary"

@@ -151,3 +151,45 @@ def test_sgd_step_and_scale_accumulate():
     ops.mask_add_(a, seed=11, scale=2.0)
     ops.mask_add_(b, seed=11, scale=-2.0)
     assert float(a.abs().max()) > 0 and float((a + b).abs().max()) == 0.0
+
+
+def test_channels_last_storage_keeps_values_binding_and_export():
+    import torch.nn as nn
+
+    from nanofed_amd.runtime.arena import ArenaLayout, ParameterArena
+
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(),
+                        nn.Conv2d(8, 4, 1), nn.Flatten(), nn.Linear(4 * 6 * 6, 5))
+    net.eval()  # keep the running statistics fixed
+    want = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(2, 3, 6, 6)
+    y_ref = net(x).detach()
+
+    layout = ArenaLayout.from_module(net).with_channels_last()
+    assert set(layout.perms) == {"0.weight", "3.weight"} and layout.bindable()
+    arena = ParameterArena(layout, "cpu", with_grad=True)
+    arena.load_state_dict(want)
+    views = arena.views()
+    for k, v in want.items():
+        assert torch.equal(views[k].to(v.dtype), v), k
+    w = views["0.weight"]
+    assert w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+    # stored order is [O, H, W, I]
+    seg = layout["0.weight"]
+    stored = arena.data[seg.offset : seg.offset + seg.numel].view(8, 3, 3, 3)
+    assert torch.equal(stored, want["0.weight"].permute(0, 2, 3, 1))
+
+    bound = arena.bind(net)
+    torch.testing.assert_close(bound(x), y_ref)
+    bound(x).sum().backward()
+    g = arena.grad_views()["0.weight"]
+    assert g.data_ptr() == dict(bound.named_parameters())["0.weight"].grad.data_ptr()
+    assert float(g.abs().sum()) > 0
+    exported = arena.state_dict()
+    for k, v in want.items():
+        assert torch.equal(exported[k], v), k
+    # another arena with the plain layout receives the same model through the state dict
+    plain = ParameterArena(ArenaLayout.from_module(net), "cpu")
+    plain.load_state_dict(arena.views())
+    assert torch.equal(plain.state_dict()["3.weight"], want["3.weight"])
