@@ -1,0 +1,353 @@
+// Training-mode BatchNorm for channels-last bf16 activations, fused with the
+// residual add and the ReLU that follow it in a ResNet block.
+//
+// The activation is a row-major matrix x[R][C] (R = N*H*W pixels, C channels,
+// C/8 a power of two between 8 and 64 lanes wide: C = 64, 128, 256, 512), so
+// the per-channel statistics are column sums:
+//
+//   nf_bn_fwd   1. partial column sums of x and x*x per workgroup (fp32)
+//               2. fixed-order final sum -> mean, 1/std; running statistics
+//               3. y = relu(x * scale + shift (+ residual)), 16-byte vectors
+//   nf_bn_bwd   1. partial sums of dz and dz * xhat, where dz = dy masked by y > 0
+//               2. final sums -> d(gamma), d(beta) (fp32)
+//               3. dx = (dz - mean(dz) - xhat * mean(dz * xhat)) * gamma / std,
+//                  and d(residual) = dz
+//
+// A lane owns 8 adjacent channels (one 16-byte load); a wave covers
+// 64 / (C/8) rows per iteration.  No atomics: results are reproducible.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nf_device.h"
+
+using namespace nfd;
+
+namespace {
+
+constexpr int kMaxBlocks = 128;
+
+__device__ __forceinline__ void load8(const bf16* p, float (&f)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = bf2f(v[k]);
+}
+
+__device__ __forceinline__ void store8(bf16* p, const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f2bf(f[k]);
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+
+// Sums a[k], b[k] over the lanes of a wave that own the same channel chunk
+// (lanes whose index differs only in the bits above log2(lpr)), then over the
+// four waves through LDS; wave 0 writes partial[block][0][c], partial[block][1][c].
+__device__ __forceinline__ void reduce_and_store(float (&a)[8], float (&b)[8], int lpr, int C,
+                                                 float* partial, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] += __shfl_xor(a[k], off, 64);
+            b[k] += __shfl_xor(b[k], off, 64);
+        }
+    }
+    // red: [4 waves][2][C]
+    if (lane < lpr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[(wave * 2 + 0) * C + lane * 8 + k] = a[k];
+            red[(wave * 2 + 1) * C + lane * 8 + k] = b[k];
+        }
+    }
+    __syncthreads();
+    float* out = partial + static_cast<long>(blockIdx.x) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        out[i] = (red[i] + red[2 * C + i]) + (red[4 * C + i] + red[6 * C + i]);
+}
+
+__global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16* x, float* partial,
+                                                               long R, int C, int lpr,
+                                                               long rows_per_block) {
+    extern __shared__ float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
+    const long r0 = blockIdx.x * rows_per_block;
+    const long r1 = min(R, r0 + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = r0 + wave * rpw + sub; r < r1; r += 4 * rpw) {
+        float v[8];
+        load8(x + r * C + chunk * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s[k] += v[k];
+            q[k] = fmaf(v[k], v[k], q[k]);
+        }
+    }
+    reduce_and_store(s, q, lpr, C, partial, red);
+}
+
+// Fixed-order sum of the per-workgroup partials of 64 channels: wave w adds a
+// quarter of the rows, wave 0 combines.  Returns the channel of this lane in
+// wave 0 (with the two sums), -1 for every other thread.
+__device__ __forceinline__ int final_sums(const float* partial, int nblocks, int C, float& s0,
+                                          float& s1) {
+    __shared__ float red[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        const int lo = (nblocks * wave) >> 2, hi = (nblocks * (wave + 1)) >> 2;
+#pragma unroll 4
+        for (int k = lo; k < hi; ++k) {
+            a += partial[static_cast<long>(k) * 2 * C + c];
+            b += partial[static_cast<long>(k) * 2 * C + C + c];
+        }
+    }
+    red[wave][0][lane] = a;
+    red[wave][1][lane] = b;
+    __syncthreads();
+    if (wave != 0 || c >= C) return -1;
+    s0 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+    s1 = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    return c;
+}
+
+// stats[0][c] = mean, stats[1][c] = 1/std (biased variance), running statistics
+// updated with the unbiased variance, as torch.nn.BatchNorm2d does.
+__global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* partial, float* stats,
+                                                             float* running_mean,
+                                                             float* running_var, int nblocks,
+                                                             int C, float inv_count,
+                                                             float unbias, float momentum,
+                                                             float eps) {
+    float s, q;
+    const int c = final_sums(partial, nblocks, C, s, q);
+    if (c < 0) return;
+    const float mean = s * inv_count;
+    const float var = fmaxf(q * inv_count - mean * mean, 0.f);
+    stats[c] = mean;
+    stats[C + c] = rsqrtf(var + eps);
+    if (running_mean != nullptr) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
+    }
+}
+
+template <bool kRelu, bool kRes>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const bf16* x, const bf16* res,
+                                                       const float* stats, const float* gamma,
+                                                       const float* beta, bf16* y, long n8,
+                                                       int C) {
+    for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
+         i += static_cast<long>(gridDim.x) * 256) {
+        const int c0 = static_cast<int>((i * 8) % C);
+        float v[8], o[8];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float sc = stats[C + c0 + k] * gamma[c0 + k];
+            o[k] = fmaf(v[k] - stats[c0 + k], sc, beta[c0 + k]);
+        }
+        if (kRes) {
+            float r[8];
+            load8(res + i * 8, r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] += r[k];
+        }
+        if (kRelu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+        }
+        store8(y + i * 8, o);
+    }
+}
+
+template <bool kRelu>
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const bf16* dy, const bf16* y,
+                                                             const bf16* x, const float* stats,
+                                                             float* partial, long R, int C,
+                                                             int lpr, long rows_per_block) {
+    extern __shared__ float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
+    const long r0 = blockIdx.x * rows_per_block;
+    const long r1 = min(R, r0 + rows_per_block);
+    float mu[8], rs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = stats[chunk * 8 + k];
+        rs[k] = stats[C + chunk * 8 + k];
+    }
+    float sb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = r0 + wave * rpw + sub; r < r1; r += 4 * rpw) {
+        const long at = r * C + chunk * 8;
+        float d[8], xv[8];
+        load8(dy + at, d);
+        load8(x + at, xv);
+        if (kRelu) {
+            float yv[8];
+            load8(y + at, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sb[k] += d[k];
+            sg[k] = fmaf(d[k], (xv[k] - mu[k]) * rs[k], sg[k]);
+        }
+    }
+    reduce_and_store(sb, sg, lpr, C, partial, red);
+}
+
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat); d(gamma), d(beta) are overwritten.
+__global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* partial, float* coef,
+                                                           float* dgamma, float* dbeta,
+                                                           int nblocks, int C, float inv_count) {
+    float sb, sg;
+    const int c = final_sums(partial, nblocks, C, sb, sg);
+    if (c < 0) return;
+    dbeta[c] = sb;
+    dgamma[c] = sg;
+    coef[c] = sb * inv_count;
+    coef[C + c] = sg * inv_count;
+}
+
+template <bool kRelu, bool kRes>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16* dy, const bf16* y,
+                                                           const bf16* x, const float* stats,
+                                                           const float* coef, const float* gamma,
+                                                           bf16* dx, bf16* dres, long n8, int C) {
+    for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
+         i += static_cast<long>(gridDim.x) * 256) {
+        const int c0 = static_cast<int>((i * 8) % C);
+        float d[8], xv[8], o[8];
+        load8(dy + i * 8, d);
+        load8(x + i * 8, xv);
+        if (kRelu) {
+            float yv[8];
+            load8(y + i * 8, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+        }
+        if (kRes) store8(dres + i * 8, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float rs = stats[C + c0 + k];
+            const float xh = (xv[k] - stats[c0 + k]) * rs;
+            o[k] = (d[k] - coef[c0 + k] - xh * coef[C + c0 + k]) * rs * gamma[c0 + k];
+        }
+        store8(dx + i * 8, o);
+    }
+}
+
+inline int lanes_per_row(int C) {
+    const int lpr = C / 8;
+    if (C % 8 != 0 || lpr < 8 || lpr > 64 || (lpr & (lpr - 1)) != 0) return 0;
+    return lpr;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// at least eight row iterations per workgroup, so the partial pass stays short
+inline int blocks_for(long R, int lpr) {
+    const long rows_per_iter = 4L * (64 / lpr) * 8;
+    long b = (R + rows_per_iter - 1) / rows_per_iter;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return static_cast<int>(b);
+}
+
+inline int grid_cap(long n8) {
+    long b = (n8 + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return static_cast<int>(b);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when the channel count is supported (C/8 a power of two in [8, 64]).
+int nf_bn_supported(int C) { return lanes_per_row(C) != 0; }
+
+int nf_bn_workspace_floats(int C) { return kMaxBlocks * 2 * C; }
+
+// stats: 2*C floats (mean, 1/std) kept for the backward pass.  running_* may
+// be null.  res may be null.  y may not alias x when relu is set (the backward
+// pass reads both).
+int nf_bn_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+              float* running_mean, float* running_var, float* stats, float* workspace, long R,
+              int C, int relu, float momentum, float eps, hipStream_t s) {
+    const int lpr = lanes_per_row(C);
+    if (lpr == 0 || R <= 0) return -1;
+    if (!al16(x) || !al16(y) || (res != nullptr && !al16(res))) return -2;
+    const int nb = blocks_for(R, lpr);
+    const long rpb = (R + nb - 1) / nb;
+    const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), lds, s,
+                       static_cast<const bf16*>(x), workspace, R, C, lpr, rpb);
+    const float unbias = R > 1 ? static_cast<float>(R) / static_cast<float>(R - 1) : 1.f;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace,
+                       stats, running_mean, running_var, nb, C, 1.f / static_cast<float>(R),
+                       unbias, momentum, eps);
+    const long n8 = R * C / 8;
+    const dim3 grid(grid_cap(n8)), block(256);
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* rp = static_cast<const bf16*>(res);
+    bf16* yp = static_cast<bf16*>(y);
+    if (relu && res != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
+    else if (relu)
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
+    else if (res != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
+    return static_cast<int>(hipGetLastError());
+}
+
+// dgamma / dbeta (fp32) are overwritten.  dres (may be null) receives the
+// gradient of the residual input.  workspace: nf_bn_workspace_floats(C) + 2*C floats.
+int nf_bn_bwd(const void* dy, const void* y, const void* x, const float* stats,
+              const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta,
+              float* workspace, long R, int C, int relu, hipStream_t s) {
+    const int lpr = lanes_per_row(C);
+    if (lpr == 0 || R <= 0) return -1;
+    if (!al16(dy) || !al16(x) || !al16(dx) || (relu && !al16(y)) || (dres != nullptr && !al16(dres)))
+        return -2;
+    const int nb = blocks_for(R, lpr);
+    const long rpb = (R + nb - 1) / nb;
+    const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
+    float* coef = workspace + static_cast<long>(kMaxBlocks) * 2 * C;
+    const bf16* dyp = static_cast<const bf16*>(dy);
+    const bf16* yp = static_cast<const bf16*>(y);
+    const bf16* xp = static_cast<const bf16*>(x);
+    if (relu)
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nb), dim3(256), lds, s, dyp, yp, xp,
+                           stats, workspace, R, C, lpr, rpb);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nb), dim3(256), lds, s, dyp, yp, xp,
+                           stats, workspace, R, C, lpr, rpb);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace, coef,
+                       dgamma, dbeta, nb, C, 1.f / static_cast<float>(R));
+    const long n8 = R * C / 8;
+    const dim3 grid(grid_cap(n8)), block(256);
+    bf16* dxp = static_cast<bf16*>(dx);
+    bf16* drp = static_cast<bf16*>(dres);
+    if (relu && dres != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
+    else if (relu)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
+    else if (dres != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // extern "C"
