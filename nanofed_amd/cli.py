@@ -61,8 +61,16 @@ def info() -> None:
 @click.option("--dp-clip", default=1.0)
 @click.option("--backend", type=click.Choice(["auto", "native", "torch"]), default="auto")
 @click.option("--base-dir", default=None, type=click.Path(), help="write models/ and metrics/ here")
+@click.option("--seq-len", default=1024, help="sequence length of token datasets")
+@click.option("--min-clients", default=1, help="quorum: valid updates needed to close a round")
+@click.option("--max-update-norm", default=0.0, help="reject updates farther than this from the global model")
+@click.option("--checkpoint-rounds", is_flag=True,
+              help="checkpoint every completed round and roll back on recoverable failures")
+@click.option("--resume", is_flag=True, help="continue from the newest model version in --base-dir")
+@click.option("--phases", is_flag=True, help="print the HIP-event timing of the round phases")
 def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_client, lr,
-        partition, alpha, dp_noise, dp_clip, backend, base_dir) -> None:
+        partition, alpha, dp_noise, dp_clip, backend, base_dir, seq_len, min_clients,
+        max_update_norm, checkpoint_rounds, resume, phases) -> None:
     """Federated rounds on the device plane (launch under torch.distributed.run for multi-GPU)."""
     from nanofed_amd.engine import DPConfig, EngineConfig, FederatedEngine
     from nanofed_amd.parallel import Communicator
@@ -73,16 +81,27 @@ def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_c
         model=model, dataset=dataset or default_ds.get(model, "synthetic_mnist"),
         num_clients=clients, num_rounds=rounds, local_epochs=local_epochs,
         batch_size=batch_size, samples_per_client=samples_per_client, learning_rate=lr,
-        partition=partition, dirichlet_alpha=alpha, backend=backend,
+        partition=partition, dirichlet_alpha=alpha, backend=backend, seq_len=seq_len,
+        min_clients=min_clients, max_update_norm=max_update_norm,
+        checkpoint_rounds=checkpoint_rounds,
         dp=DPConfig(max_gradient_norm=dp_clip, noise_multiplier=dp_noise) if dp_noise > 0 else None,
     )
     comm = Communicator.from_env()
+    if (checkpoint_rounds or resume) and not base_dir:
+        raise click.UsageError("--checkpoint-rounds and --resume need --base-dir")
     engine = FederatedEngine(cfg, comm=comm, base_dir=Path(base_dir) if base_dir else None)
+    if resume:
+        start = engine.resume()
+        if comm.is_root:
+            click.echo(json.dumps({"resumed_at_round": start}))
     for report in engine.run():
         if comm.is_root:
-            click.echo(json.dumps({"round": report.round_id, "status": report.status,
-                                   "clients": report.num_clients, **report.agg_metrics,
-                                   "wall_s": round(report.wall_s, 4)}))
+            line = {"round": report.round_id, "status": report.status,
+                    "clients": report.num_clients, **report.agg_metrics,
+                    "wall_s": round(report.wall_s, 4)}
+            if phases:
+                line["phases_ms"] = {k: round(v, 3) for k, v in report.phases_ms.items()}
+            click.echo(json.dumps(line))
     if comm.is_root:
         click.echo(json.dumps({"eval": engine.evaluate()}))
     comm.close()

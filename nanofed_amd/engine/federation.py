@@ -426,7 +426,7 @@ class FederatedEngine:
                 self.global_arena.load_state_dict(state["model_state"])
                 flag[0] = 1.0
                 flag[1] = float(state.get("next_round", self.round_id))
-            elif self._recovery._recovery.should_recover(failure):
+            elif self._recovery.is_recoverable(failure):
                 # nothing completed yet: the untouched initial model is the recovery point
                 flag[0] = 1.0
                 flag[1] = float(self.round_id)

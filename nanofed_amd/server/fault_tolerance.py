@@ -222,6 +222,10 @@ class FaultTolerantCoordinator:
     ) -> tuple[CheckpointMetadata, dict[str, Any]] | None:
         return self._state_store.load_checkpoint(round_id)
 
+    def is_recoverable(self, failure: Exception) -> bool:
+        """The recovery strategy's verdict on ``failure``."""
+        return self._recovery.should_recover(failure)
+
     def handle_failure(
         self, failure: Exception, current_round: int
     ) -> tuple[CheckpointMetadata, dict[str, Any]] | None:
