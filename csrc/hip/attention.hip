@@ -93,14 +93,21 @@ __device__ __forceinline__ void tile_store(char* lds, int pitch, const TileRegs&
 // ---------------------------------------------------------------------------
 constexpr int kFwdLds = 2 * kStage * (kRowPitch + kTrPitch);
 
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16* qkv, bf16* out, float* lse,
-                                                       int T, int H) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// KG groups of four waves share one 128-query tile: group g takes the key stages
+// g, g + KG, ... (each group stages its own K/V tiles), and the partial
+// (max, sum, O) triples are merged through LDS at the end.  More waves per SIMD
+// hide the LDS / exp / MFMA latencies of a single wave's dependent chain.
+template <int KG>
+__global__ void __launch_bounds__(256 * KG) attn_fwd_kernel(const bf16* qkv, bf16* out, float* lse,
+                                                            int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    char* smem = smem_all + grp * kFwdLds;
     auto k_buf = [&](int i) { return smem + (i & 1) * kStage * kRowPitch; };
     auto v_buf = [&](int i) { return smem + 2 * kStage * kRowPitch + (i & 1) * kStage * kTrPitch; };
     const int qt = gridDim.x - 1 - blockIdx.x;  // long tiles first
     const int b = blockIdx.y / H, h = blockIdx.y % H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
     const int C = H * kHd;
     const long ld = 3L * C;
     const bf16* qb = qkv + static_cast<long>(b) * T * ld + h * kHd;
@@ -115,66 +122,105 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16* qkv, bf16* ou
     float m = kNegBig, l = 0.f;
     const float sc2 = kScale * kLog2e;
     const int stages = 2 * (qt + 1);
+    const int iters = (stages + KG - 1) / KG;  // the same for every group: barriers stay aligned
 
-    TileRegs kr = tile_load(kb, ld, 0, tid), vr = tile_load(vb, ld, 0, tid);
-    tile_store(k_buf(0), kRowPitch, kr, tid);
-    tile_store(v_buf(0), kTrPitch, vr, tid);
+    TileRegs kr, vr;
+    if (grp < stages) {
+        kr = tile_load(kb, ld, grp * kStage, tid);
+        vr = tile_load(vb, ld, grp * kStage, tid);
+        tile_store(k_buf(0), kRowPitch, kr, tid);
+        tile_store(v_buf(0), kTrPitch, vr, tid);
+    }
     __syncthreads();
-    for (int st = 0; st < stages; ++st) {
-        const char* Ks = k_buf(st);
-        const char* Vs = v_buf(st);
-        if (st + 1 < stages) {
-            kr = tile_load(kb, ld, (st + 1) * kStage, tid);
-            vr = tile_load(vb, ld, (st + 1) * kStage, tid);
+    for (int it = 0; it < iters; ++it) {
+        const int st = it * KG + grp;
+        const bool next = st + KG < stages;
+        const char* Ks = k_buf(it);
+        const char* Vs = v_buf(it);
+        if (next) {
+            kr = tile_load(kb, ld, (st + KG) * kStage, tid);
+            vr = tile_load(vb, ld, (st + KG) * kStage, tid);
         }
+        if (st < stages) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = st * kStage + sub * 32;
-            if (key0 > q0 + 31) continue;  // wave-uniform: nothing visible in this tile
-            f32x16 s = {0};
+            for (int sub = 0; sub < 2; ++sub) {
+                const int key0 = st * kStage + sub * 32;
+                if (key0 > q0 + 31) continue;  // wave-uniform: nothing visible in this tile
+                f32x16 s = {0};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s = mfma32(row_frag(Ks, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), qf[ks], s);
-            // raw scores; the 1/sqrt(d) * log2(e) factor is folded into the exponent
-            const bool diag = key0 + 31 > q0;
-            float mx = kNegBig;
+                for (int ks = 0; ks < 4; ++ks)
+                    s = mfma32(row_frag(Ks, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), qf[ks], s);
+                // raw scores; the 1/sqrt(d) * log2(e) factor is folded into the exponent
+                const bool diag = key0 + 31 > q0;
+                float mx = kNegBig;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (diag && key0 + acc_row(r, lane) > q0 + n) s[r] = kNegBig;
-                mx = fmaxf(mx, s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    if (diag && key0 + acc_row(r, lane) > q0 + n) s[r] = kNegBig;
+                    mx = fmaxf(mx, s[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                // the running maximum rarely moves after the first tiles: rescale the
+                // accumulators only when some query of the wave needs it
+                if (__any(mx > m)) {
+                    const float mn = fmaxf(m, mx);
+                    const float alpha = fast_exp2((m - mn) * sc2);
+                    m = mn;
+                    l *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                }
+                const float msc = m * sc2;
+                float rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(fmaf(s[r], sc2, -msc));
+                    s[r] = p;
+                    rs += p;
+                }
+                l += rs;
+                const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
+                o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 0, lane), p0, o0);
+                o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 32, lane), p0, o1);
+                o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 0, lane), p1, o0);
+                o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 32, lane), p1, o1);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // the running maximum rarely moves after the first tiles: rescale the
-            // accumulators only when some query of the wave needs it
-            if (__any(mx > m)) {
-                const float mn = fmaxf(m, mx);
-                const float alpha = fast_exp2((m - mn) * sc2);
-                m = mn;
-                l *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            }
-            const float msc = m * sc2;
-            float rs = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(s[r], sc2, -msc));
-                s[r] = p;
-                rs += p;
-            }
-            l += rs;
-            const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
-            o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 0, lane), p0, o0);
-            o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 32, lane), p0, o1);
-            o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 0, lane), p1, o0);
-            o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 32, lane), p1, o1);
         }
-        if (st + 1 < stages) {
-            tile_store(k_buf(st + 1), kRowPitch, kr, tid);
-            tile_store(v_buf(st + 1), kTrPitch, vr, tid);
+        if (next) {
+            tile_store(k_buf(it + 1), kRowPitch, kr, tid);
+            tile_store(v_buf(it + 1), kTrPitch, vr, tid);
         }
         __syncthreads();
     }
+    // merge the groups pairwise: the upper half of the live groups parks its
+    // (m, l, O) in its own LDS region, the lower half folds it in
+    for (int half = KG / 2; half >= 1; half >>= 1) {
+        if (grp >= half && grp < 2 * half) {
+            float* park = reinterpret_cast<float*>(smem);
+            park[0 * 256 + tid] = m;
+            park[1 * 256 + tid] = l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                park[(2 + r) * 256 + tid] = o0[r];
+                park[(18 + r) * 256 + tid] = o1[r];
+            }
+        }
+        __syncthreads();
+        if (grp < half) {
+            const float* park = reinterpret_cast<const float*>(smem_all + (grp + half) * kFwdLds);
+            const float m2 = park[0 * 256 + tid], l2 = park[1 * 256 + tid];
+            const float mn = fmaxf(m, m2);
+            const float a1 = fast_exp2((m - mn) * sc2), a2 = fast_exp2((m2 - mn) * sc2);
+            m = mn;
+            l = l * a1 + l2 * a2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] = o0[r] * a1 + park[(2 + r) * 256 + tid] * a2;
+                o1[r] = o1[r] * a1 + park[(18 + r) * 256 + tid] * a2;
+            }
+        }
+        __syncthreads();
+    }
+    if (grp != 0) return;
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
     bf16* orow = out + (static_cast<long>(b) * T + q0 + n) * C + h * kHd;
@@ -436,6 +482,15 @@ inline int set_lds(const void* fn, int bytes) {
                : -20;
 }
 
+template <int KG>
+int launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hipStream_t s) {
+    static const int attr = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<KG>), KG * kFwdLds);
+    if (attr) return attr;
+    hipLaunchKernelGGL(attn_fwd_kernel<KG>, dim3(T / 128, B * H), dim3(256 * KG), KG * kFwdLds, s,
+                       static_cast<const bf16*>(qkv), static_cast<bf16*>(out), lse, T, H);
+    return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -443,14 +498,18 @@ extern "C" {
 // Sequence lengths the kernels accept: a multiple of the 128-row workgroup tile.
 int nf_attn_seq_multiple() { return 128; }
 
+// Wave groups per 128-query tile (1, 2 or 4) for the forward kernel; tuning hook.
+static int g_fwd_kg = 2;
+void nf_attn_set_split(int fwd_kg) {
+    if (fwd_kg == 1 || fwd_kg == 2 || fwd_kg == 4) g_fwd_kg = fwd_kg;
+}
+
 int nf_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hipStream_t s) {
     if (B <= 0 || H <= 0 || T <= 0 || T % 128 != 0) return -1;
     if (!ok16(qkv) || !ok16(out)) return -2;
-    static const int attr = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel), kFwdLds);
-    if (attr) return attr;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(T / 128, B * H), dim3(256), kFwdLds, s,
-                       static_cast<const bf16*>(qkv), static_cast<bf16*>(out), lse, T, H);
-    return static_cast<int>(hipGetLastError());
+    if (g_fwd_kg == 4) return launch_fwd<4>(qkv, out, lse, B, T, H, s);
+    if (g_fwd_kg == 2) return launch_fwd<2>(qkv, out, lse, B, T, H, s);
+    return launch_fwd<1>(qkv, out, lse, B, T, H, s);
 }
 
 // delta: B*H*T floats of scratch.  dqkv is fully overwritten.

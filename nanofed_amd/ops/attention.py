@@ -23,6 +23,7 @@ _SIGS = {
     "nf_attn_seq_multiple": ([], I),
     "nf_attn_fwd": ([P, P, P, I, I, I, P], I),
     "nf_attn_bwd": ([P, P, P, P, P, P, I, I, I, P], I),
+    "nf_attn_set_split": ([I], None),
 }
 _fns: dict[str, object] = {}
 HEAD_DIM = 64
@@ -56,6 +57,14 @@ def _check(qkv: torch.Tensor, batch: int, seq: int, heads: int) -> int:
         if seq % mult:
             raise DeviceError(f"sequence length {seq} is not a multiple of {mult}")
     return C
+
+
+def set_forward_split(groups: int) -> None:
+    """Wave groups (1, 2 or 4) that share one 128-query tile in the forward
+    kernel, each taking every ``groups``-th key stage (tuning hook)."""
+    if groups not in (1, 2, 4):
+        raise DeviceError("the forward split must be 1, 2 or 4")
+    _fn("nf_attn_set_split")(groups)
 
 
 def backward_scratch(batch: int, heads: int, seq: int, device: torch.device) -> torch.Tensor:
