@@ -93,12 +93,59 @@ __device__ __forceinline__ void tile_store(char* lds, int pitch, const TileRegs&
 // ---------------------------------------------------------------------------
 constexpr int kFwdLds = 2 * kStage * (kRowPitch + kTrPitch);
 
+// One 32-key x 32-query tile of the forward pass for one wave: S^T = K Q^T,
+// online softmax update of (m, l), O^T += V^T P^T.  kDiag: the tile straddles
+// the diagonal, so keys after the query are masked.
+template <bool kDiag>
+__device__ __forceinline__ void fwd_subtile(const char* Ks, const char* Vs, int sub, int key0,
+                                            int q0, int lane, float sc2, const bf16x8 (&qf)[4],
+                                            float& m, float& l, f32x16& o0, f32x16& o1) {
+    const int n = lane & 31, hh = lane >> 5;
+    f32x16 s = {0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        s = mfma32(row_frag(Ks, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), qf[ks], s);
+    // raw scores; the 1/sqrt(d) * log2(e) factor is folded into the exponent
+    float mx = kNegBig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (kDiag && key0 + acc_row(r, lane) > q0 + n) s[r] = kNegBig;
+        mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // the running maximum rarely moves after the first tiles: rescale the
+    // accumulators only when some query of the wave needs it
+    if (__any(mx > m)) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = fast_exp2((m - mn) * sc2);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    const float msc = m * sc2;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(s[r], sc2, -msc));
+        s[r] = p;
+        rs += p;
+    }
+    l += rs;
+    const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
+    o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 0, lane), p0, o0);
+    o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 32, lane), p0, o1);
+    o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 0, lane), p1, o0);
+    o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 32, lane), p1, o1);
+}
+
 // KG groups of four waves share one 128-query tile: group g takes the key stages
 // g, g + KG, ... (each group stages its own K/V tiles), and the partial
 // (max, sum, O) triples are merged through LDS at the end.  More waves per SIMD
 // hide the LDS / exp / MFMA latencies of a single wave's dependent chain.
 template <int KG>
-__global__ void __launch_bounds__(256 * KG) attn_fwd_kernel(const bf16* qkv, bf16* out, float* lse,
+__global__ void __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(4, 4)))
+attn_fwd_kernel(const bf16* qkv, bf16* out, float* lse,
                                                             int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
@@ -146,43 +193,11 @@ __global__ void __launch_bounds__(256 * KG) attn_fwd_kernel(const bf16* qkv, bf1
             for (int sub = 0; sub < 2; ++sub) {
                 const int key0 = st * kStage + sub * 32;
                 if (key0 > q0 + 31) continue;  // wave-uniform: nothing visible in this tile
-                f32x16 s = {0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    s = mfma32(row_frag(Ks, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), qf[ks], s);
-                // raw scores; the 1/sqrt(d) * log2(e) factor is folded into the exponent
-                const bool diag = key0 + 31 > q0;
-                float mx = kNegBig;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (diag && key0 + acc_row(r, lane) > q0 + n) s[r] = kNegBig;
-                    mx = fmaxf(mx, s[r]);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                // the running maximum rarely moves after the first tiles: rescale the
-                // accumulators only when some query of the wave needs it
-                if (__any(mx > m)) {
-                    const float mn = fmaxf(m, mx);
-                    const float alpha = fast_exp2((m - mn) * sc2);
-                    m = mn;
-                    l *= alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-                }
-                const float msc = m * sc2;
-                float rs = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = fast_exp2(fmaf(s[r], sc2, -msc));
-                    s[r] = p;
-                    rs += p;
-                }
-                l += rs;
-                const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
-                o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 0, lane), p0, o0);
-                o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32, 32, lane), p0, o1);
-                o0 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 0, lane), p1, o0);
-                o1 = mfma32(tr_frag_perm(Vs, kTrPitch, sub * 32 + 16, 32, lane), p1, o1);
+                // only the tiles on the diagonal need the per-element causal test
+                if (key0 + 31 > q0)
+                    fwd_subtile<true>(Ks, Vs, sub, key0, q0, lane, sc2, qf, m, l, o0, o1);
+                else
+                    fwd_subtile<false>(Ks, Vs, sub, key0, q0, lane, sc2, qf, m, l, o0, o1);
             }
         }
         if (next) {
@@ -267,6 +282,41 @@ __global__ void __launch_bounds__(256) attn_bwd_delta_kernel(const bf16* out, co
     }
 }
 
+// P = exp2(S * sc2 - lse2) and dS = P * (dP - delta) * scale for one accumulator
+// tile, in place (s <- P, dp <- dS).  kRows: the per-query values (lse2, delta)
+// vary along the accumulator rows and are read from LDS (dK/dV kernel); otherwise
+// the lane owns one query and passes them as the first elements.  kDiag: apply
+// the causal mask (query index < key index -> 0).
+template <bool kDiag, bool kRows>
+__device__ __forceinline__ void bwd_probs(f32x16& s, f32x16& dp, const float* lse2,
+                                          const float* del, float sc2, int row0, int col, int hh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float lv[4], dv[4];
+        if (kRows) {
+            const float4 l4 = *reinterpret_cast<const float4*>(lse2 + 8 * g + 4 * hh);
+            const float4 d4 = *reinterpret_cast<const float4*>(del + 8 * g + 4 * hh);
+            lv[0] = l4.x; lv[1] = l4.y; lv[2] = l4.z; lv[3] = l4.w;
+            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lv[e] = lse2[0]; dv[e] = del[0]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float p = fast_exp2(fmaf(s[r], sc2, -lv[e]));
+            // kRows: rows are queries, the lane's column a key; else rows are keys
+            if (kDiag) {
+                const int rr = row0 + 8 * g + 4 * hh + e;
+                if (kRows ? (rr < col) : (rr > col)) p = 0.f;
+            }
+            s[r] = p;
+            dp[r] = p * (dp[r] - dv[e]) * kScale;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // LDS per stage: Q and dO tiles, each in both pitches (row reads feed S and dP,
 // transposing reads feed dK and dV), plus lse and delta of the 64 queries.
@@ -274,7 +324,8 @@ constexpr int kTileBoth = kStage * (kRowPitch + kTrPitch);
 constexpr int kDkvStage = 2 * kTileBoth + 2 * kStage * 4;
 constexpr int kDkvLds = 2 * kDkvStage;
 
-__global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const bf16* qkv, const bf16* dout,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+attn_bwd_dkdv_kernel(const bf16* qkv, const bf16* dout,
                                                             const float* lse, const float* delta,
                                                             bf16* dqkv, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -340,22 +391,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const bf16* qkv, con
                 dp = mfma32(row_frag(Drow, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), vf[ks], dp);
             }
             // s[r], dp[r]: query qs0 + acc_row(r), key key0 + n
-            const bool diag = qs0 < key0 + 31;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 l4 = *reinterpret_cast<const float4*>(lse2 + sub * 32 + 8 * g + 4 * hh);
-                const float4 d4 = *reinterpret_cast<const float4*>(del + sub * 32 + 8 * g + 4 * hh);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float p = fast_exp2(s[r] * sc2 - lv[e]);
-                    if (diag && qs0 + 8 * g + 4 * hh + e < key0 + n) p = 0.f;
-                    s[r] = p;
-                    dp[r] = p * (dp[r] - dv[e]) * kScale;
-                }
-            }
+            if (qs0 < key0 + 31)
+                bwd_probs<true, true>(s, dp, lse2 + sub * 32, del + sub * 32, sc2, qs0, key0 + n, hh);
+            else
+                bwd_probs<false, true>(s, dp, lse2 + sub * 32, del + sub * 32, sc2, qs0, key0 + n, hh);
             const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
             const bf16x8 s0 = pack8(dp, 0), s1 = pack8(dp, 8);
             dv0 = mfma32(p0, tr_frag_perm(Dtr, kTrPitch, sub * 32, 0, lane), dv0);
@@ -389,7 +428,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const bf16* qkv, con
 constexpr int kDqStage = kTileBoth + kStage * kRowPitch;
 constexpr int kDqLds = 2 * kDqStage;
 
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const bf16* qkv, const bf16* dout,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+attn_bwd_dq_kernel(const bf16* qkv, const bf16* dout,
                                                           const float* lse, const float* delta,
                                                           bf16* dqkv, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -443,13 +483,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const bf16* qkv, const
                 dp = mfma32(row_frag(Vrow, kRowPitch, sub * 32 + n, ks * 16 + 8 * hh), dof[ks], dp);
             }
             // s[r], dp[r]: key key0 + acc_row(r), query q0 + n
-            const bool diag = key0 + 31 > q0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = fast_exp2(s[r] * sc2 - lse2);
-                if (diag && key0 + acc_row(r, lane) > q0 + n) p = 0.f;
-                dp[r] = p * (dp[r] - del) * kScale;
-            }
+            if (key0 + 31 > q0)
+                bwd_probs<true, false>(s, dp, &lse2, &del, sc2, key0, q0 + n, hh);
+            else
+                bwd_probs<false, false>(s, dp, &lse2, &del, sc2, key0, q0 + n, hh);
             const bf16x8 s0 = pack8(dp, 0), s1 = pack8(dp, 8);
             dq0 = mfma32(tr_frag_perm(Ktr, kTrPitch, sub * 32, 0, lane), s0, dq0);
             dq1 = mfma32(tr_frag_perm(Ktr, kTrPitch, sub * 32, 32, lane), s0, dq1);
