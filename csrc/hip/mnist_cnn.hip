@@ -566,7 +566,8 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fc1_wgrad_kernel(MnistCtx c, int step) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+fc1_wgrad_kernel(MnistCtx c, int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_dh = smem;                    // [64 b][128 j]
     char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
@@ -652,7 +653,8 @@ __device__ __forceinline__ int dg_swz(int pr, int pc, int part) {
     return (pr * kDgPatchCols + pc) * 128 + ((part ^ (((pc >> 1) + 5 * pr) & 7)) << 4);
 }
 
-__global__ void __launch_bounds__(256) conv2_dgrad_kernel(MnistCtx c, int idx_off) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv2_dgrad_kernel(MnistCtx c, int idx_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);       // normalised input image
     int* soff = reinterpret_cast<int*>(xs + 784);                     // a1 pixel -> offset in xs
