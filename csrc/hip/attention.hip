@@ -152,8 +152,12 @@ attn_fwd_kernel(const bf16* qkv, bf16* out, float* lse,
     char* smem = smem_all + grp * kFwdLds;
     auto k_buf = [&](int i) { return smem + (i & 1) * kStage * kRowPitch; };
     auto v_buf = [&](int i) { return smem + 2 * kStage * kRowPitch + (i & 1) * kStage * kTrPitch; };
-    const int qt = gridDim.x - 1 - blockIdx.x;  // long tiles first
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    // grid = (batch*head, tile): workgroups go to the XCDs round-robin by linear
+    // id, so every tile of one head lands on the same XCD and its K/V stay in
+    // that XCD's L2; the long tiles of all heads are dispatched first
+    const int qt = gridDim.y - 1 - blockIdx.y;
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh % H;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
     const int C = H * kHd;
     const long ld = 3L * C;
@@ -251,7 +255,7 @@ attn_fwd_kernel(const bf16* qkv, bf16* out, float* lse,
         *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * hh) = c;
     }
     if (hh == 0)
-        lse[(static_cast<long>(blockIdx.y)) * T + q0 + n] = m * kScale + __logf(l);
+        lse[(static_cast<long>(bh)) * T + q0 + n] = m * kScale + __logf(l);
 }
 
 // ---------------------------------------------------------------------------
@@ -329,15 +333,16 @@ attn_bwd_dkdv_kernel(const bf16* qkv, const bf16* dout,
                                                             const float* lse, const float* delta,
                                                             bf16* dqkv, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int kt = blockIdx.x;  // key tile 0 sees every query: longest first
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int kt = blockIdx.y;  // key tile 0 sees every query: longest first
+    const int bh = blockIdx.x;  // all tiles of a head on one XCD (see attn_fwd_kernel)
+    const int b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
     const int C = H * kHd;
     const long ld = 3L * C;
     const bf16* qb = qkv + static_cast<long>(b) * T * ld + h * kHd;
     const bf16* dob = dout + static_cast<long>(b) * T * C + h * kHd;
-    const float* lseb = lse + static_cast<long>(blockIdx.y) * T;
-    const float* delb = delta + static_cast<long>(blockIdx.y) * T;
+    const float* lseb = lse + static_cast<long>(bh) * T;
+    const float* delb = delta + static_cast<long>(bh) * T;
     const int key0 = kt * 128 + wave * 32;
     // K and V rows of this wave's keys: B operands of S = Q K^T and dP = dO V^T
     bf16x8 kf[4], vf[4];
@@ -433,8 +438,9 @@ attn_bwd_dq_kernel(const bf16* qkv, const bf16* dout,
                                                           const float* lse, const float* delta,
                                                           bf16* dqkv, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int qt = gridDim.x - 1 - blockIdx.x;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int qt = gridDim.y - 1 - blockIdx.y;
+    const int bh = blockIdx.x;  // all tiles of a head on one XCD (see attn_fwd_kernel)
+    const int b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
     const int C = H * kHd;
     const long ld = 3L * C;
@@ -449,8 +455,8 @@ attn_bwd_dq_kernel(const bf16* qkv, const bf16* dout,
         dof[ks] = *reinterpret_cast<const bf16x8*>(
             dout + (static_cast<long>(b) * T + q0 + n) * C + h * kHd + ks * 16 + 8 * hh);
     }
-    const float lse2 = lse[static_cast<long>(blockIdx.y) * T + q0 + n] * kLog2e;
-    const float del = delta[static_cast<long>(blockIdx.y) * T + q0 + n];
+    const float lse2 = lse[static_cast<long>(bh) * T + q0 + n] * kLog2e;
+    const float del = delta[static_cast<long>(bh) * T + q0 + n];
     f32x16 dq0 = {0}, dq1 = {0};
     const float sc2 = kScale * kLog2e;
     const int stages = 2 * (qt + 1);
@@ -523,7 +529,7 @@ template <int KG>
 int launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hipStream_t s) {
     static const int attr = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<KG>), KG * kFwdLds);
     if (attr) return attr;
-    hipLaunchKernelGGL(attn_fwd_kernel<KG>, dim3(T / 128, B * H), dim3(256 * KG), KG * kFwdLds, s,
+    hipLaunchKernelGGL(attn_fwd_kernel<KG>, dim3(B * H, T / 128), dim3(256 * KG), KG * kFwdLds, s,
                        static_cast<const bf16*>(qkv), static_cast<bf16*>(out), lse, T, H);
     return static_cast<int>(hipGetLastError());
 }
@@ -561,10 +567,10 @@ int nf_attn_bwd(const void* qkv, const void* out, const float* lse, const void* 
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(static_cast<unsigned>((tasks + 31) / 32)), dim3(256),
                        0, s, static_cast<const bf16*>(out), static_cast<const bf16*>(dout), delta,
                        B, T, H);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(T / 128, B * H), dim3(256), kDkvLds, s,
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(B * H, T / 128), dim3(256), kDkvLds, s,
                        static_cast<const bf16*>(qkv), static_cast<const bf16*>(dout), lse, delta,
                        static_cast<bf16*>(dqkv), T, H);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(T / 128, B * H), dim3(256), kDqLds, s,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H, T / 128), dim3(256), kDqLds, s,
                        static_cast<const bf16*>(qkv), static_cast<const bf16*>(dout), lse, delta,
                        static_cast<bf16*>(dqkv), T, H);
     return static_cast<int>(hipGetLastError());
