@@ -8,10 +8,10 @@
 //                       token; d(wpe)[t] = sum over the batch
 //   nf_ln_fwd           optional residual add (x_out = x_in + delta) fused with
 //                       LayerNorm; one wave per row, the row lives in registers
-//   nf_ln_bwd           d(x) (+ incoming residual gradient) and per-workgroup
-//                       partial d(gamma), d(beta) and column sums of d(x) (= bias
-//                       gradient of the projection feeding the residual stream); a
-//                       second launch sums the partials in a fixed order
+//   nf_ln_bwd           d(x) (+ incoming residual gradient), one wave per row; then a
+//                       column pass for d(gamma), d(beta) and the column sums of d(x)
+//                       (= bias gradient of the projection feeding the residual
+//                       stream), whose partials a third launch sums in a fixed order
 //   nf_gelu_fwd/bwd     tanh-GELU on the pre-activation (the bias comes from the GEMM
 //                       epilogue); nf_gelu_bwd_colsum also produces the bias gradient
 //                       of the layer in front of it
@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(256) embed_bwd_wpe_kernel(const bf16* dx, bf16
 }
 
 // ---------------------------------------------------------------------------
-template <bool kHasDelta>
+// NCH = ceil(C / 256): the number of 4-value chunks a lane holds of its row.
+template <bool kHasDelta, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf16* delta,
                                                      bf16* x_out, const bf16* gamma,
                                                      const bf16* beta, bf16* y, float* mean,
@@ -130,10 +131,10 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf1
     const int row = blockIdx.x * 4 + wave;
     if (row >= R) return;
     const long base = static_cast<long>(row) * C;
-    float v[kLnMaxChunks][4];
+    float v[NCH][4];
     float s = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < kLnMaxChunks; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = ch * 256 + lane * 4;
         if (c0 < C) {
             load4(x_in + base + c0, v[ch]);
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf1
     const float mu = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < kLnMaxChunks; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = ch * 256 + lane * 4;
         if (c0 < C) {
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf1
     const float rs = rsqrtf(wave_sum(q) / C + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-    for (int ch = 0; ch < kLnMaxChunks; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = ch * 256 + lane * 4;
         if (c0 < C) {
             float g[4], b[4], o[4];
@@ -179,87 +180,103 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf1
     }
 }
 
-// Workgroup b owns rows [b*rpb, (b+1)*rpb); wave w takes every 4th of them.
-// partial[b][0][c] = sum dy*xhat, partial[b][1][c] = sum dy, partial[b][2][c] =
-// sum dx over the block's rows (dx is the gradient of the residual stream, so
-// its column sums are the bias gradient of the projection that wrote into it).
-template <bool kHasRes>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16* dy, const bf16* x,
-                                                     const bf16* gamma, const float* mean,
-                                                     const float* rstd, const bf16* dres,
-                                                     bf16* dx, float* partial, int R, int C,
-                                                     int rpb) {
-    extern __shared__ float red[];  // [4 waves][3][C]
+// d(x) of one row per wave (the row stays in registers), plus the incoming
+// residual gradient.
+template <bool kHasRes, int NCH>
+__global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const bf16* dy, const bf16* x,
+                                                        const bf16* gamma, const float* mean,
+                                                        const float* rstd, const bf16* dres,
+                                                        bf16* dx, int R, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[kLnMaxChunks][4], db[kLnMaxChunks][4], ds[kLnMaxChunks][4], g[kLnMaxChunks][4];
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    const long base = static_cast<long>(row) * C;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NCH][4], dyw[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < kLnMaxChunks; ++ch) {
-        const int c0 = ch * 256 + lane * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { dg[ch][i] = 0.f; db[ch][i] = 0.f; ds[ch][i] = 0.f; g[ch][i] = 0.f; }
-        if (c0 < C) load4(gamma + c0, g[ch]);
-    }
-    const int row_end = min(R, (static_cast<int>(blockIdx.x) + 1) * rpb);
-    for (int row = blockIdx.x * rpb + wave; row < row_end; row += 4) {
-        const long base = static_cast<long>(row) * C;
-        const float mu = mean[row], rs = rstd[row];
-        float xh[kLnMaxChunks][4], dyw[kLnMaxChunks][4];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < kLnMaxChunks; ++ch) {
-            const int c0 = ch * 256 + lane * 4;
-            if (c0 < C) {
-                float xv[4], dv[4];
-                load4(x + base + c0, xv);
-                load4(dy + base + c0, dv);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xh[ch][i] = (xv[i] - mu) * rs;
-                    dyw[ch][i] = dv[i] * g[ch][i];
-                    s1 += dyw[ch][i];
-                    s2 += dyw[ch][i] * xh[ch][i];
-                    dg[ch][i] += dv[i] * xh[ch][i];
-                    db[ch][i] += dv[i];
-                }
-            }
-        }
-        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
-#pragma unroll
-        for (int ch = 0; ch < kLnMaxChunks; ++ch) {
-            const int c0 = ch * 256 + lane * 4;
-            if (c0 < C) {
-                float o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (dyw[ch][i] - m1 - xh[ch][i] * m2) * rs;
-                if (kHasRes) {
-                    float r[4];
-                    load4(dres + base + c0, r);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] += r[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ds[ch][i] += o[i];
-                store4(dx + base + c0, o);
-            }
-        }
-    }
-    float* mine = red + wave * 3 * C;
-#pragma unroll
-    for (int ch = 0; ch < kLnMaxChunks; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = ch * 256 + lane * 4;
         if (c0 < C) {
+            float xv[4], dv[4], g[4];
+            load4(x + base + c0, xv);
+            load4(dy + base + c0, dv);
+            load4(gamma + c0, g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                mine[c0 + i] = dg[ch][i];
-                mine[C + c0 + i] = db[ch][i];
-                mine[2 * C + c0 + i] = ds[ch][i];
+                xh[ch][i] = (xv[i] - mu) * rs;
+                dyw[ch][i] = dv[i] * g[i];
+                s1 += dyw[ch][i];
+                s2 += dyw[ch][i] * xh[ch][i];
             }
         }
     }
+    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = ch * 256 + lane * 4;
+        if (c0 < C) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (dyw[ch][i] - m1 - xh[ch][i] * m2) * rs;
+            if (kHasRes) {
+                float r[4];
+                load4(dres + base + c0, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += r[i];
+            }
+            store4(dx + base + c0, o);
+        }
+    }
+}
+
+// Column sums for d(gamma) = sum dy*xhat, d(beta) = sum dy and, of the finished
+// d(x), its column sums (the bias gradient of the projection in front of the
+// residual).  Workgroup (cx, chunk): 512 columns (8 per lane), the rows of the
+// chunk, wave w every 4th row.  partial[chunk][0..2][c].
+__global__ void __launch_bounds__(256) ln_bwd_cols_kernel(const bf16* dy, const bf16* x,
+                                                          const bf16* dx, const float* mean,
+                                                          const float* rstd, float* partial,
+                                                          int R, int C, int rows_per_chunk) {
+    __shared__ float red[4][3][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + lane * 8;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(R, r0 + rows_per_chunk);
+    float ag[8], ab[8], as[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; as[k] = 0.f; }
+    if (c < C) {
+#pragma unroll 2
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const long at = static_cast<long>(r) * C + c;
+            const float mu = mean[r], rs = rstd[r];
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + at);
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + at);
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(dx + at);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float d = bf2f(dv[k]);
+                ag[k] = fmaf(d, (bf2f(xv[k]) - mu) * rs, ag[k]);
+                ab[k] += d;
+                as[k] += bf2f(ov[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[wave][0][lane * 8 + k] = ag[k];
+        red[wave][1][lane * 8 + k] = ab[k];
+        red[wave][2][lane * 8 + k] = as[k];
+    }
     __syncthreads();
-    float* out = partial + static_cast<long>(blockIdx.x) * 3 * C;
-    for (int i = threadIdx.x; i < 3 * C; i += 256)
-        out[i] = (red[i] + red[3 * C + i]) + (red[6 * C + i] + red[9 * C + i]);
+    float* out = partial + static_cast<long>(blockIdx.y) * 3 * C;
+    for (int i = threadIdx.x; i < 3 * 512; i += 256) {
+        const int which = i / 512, col = blockIdx.x * 512 + (i % 512);
+        if (col < C)
+            out[which * C + col] = (red[0][which][i % 512] + red[1][which][i % 512]) +
+                                   (red[2][which][i % 512] + red[3][which][i % 512]);
+    }
 }
 
 // 64 columns per workgroup; wave w sums a quarter of the partial rows.
@@ -561,53 +578,69 @@ int nf_ln_fwd(const void* x_in, const void* delta, void* x_out, const void* gamm
     if (!aligned(x_in, 8) || !aligned(y, 8) || !aligned(gamma, 8) || !aligned(beta, 8)) return -2;
     if (delta != nullptr && (x_out == nullptr || !aligned(delta, 8) || !aligned(x_out, 8))) return -2;
     const dim3 grid((R + 3) / 4), block(256);
-    if (delta != nullptr)
-        hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, s, static_cast<const bf16*>(x_in),
-                           static_cast<const bf16*>(delta), static_cast<bf16*>(x_out),
-                           static_cast<const bf16*>(gamma), static_cast<const bf16*>(beta),
-                           static_cast<bf16*>(y), mean, rstd, R, C, eps);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, s, static_cast<const bf16*>(x_in),
-                           nullptr, nullptr, static_cast<const bf16*>(gamma),
-                           static_cast<const bf16*>(beta), static_cast<bf16*>(y), mean, rstd, R,
-                           C, eps);
+    const bf16* xi = static_cast<const bf16*>(x_in);
+    const bf16* dl = static_cast<const bf16*>(delta);
+    bf16* xo = static_cast<bf16*>(x_out);
+    const bf16* ga = static_cast<const bf16*>(gamma);
+    const bf16* be = static_cast<const bf16*>(beta);
+    bf16* yo = static_cast<bf16*>(y);
+#define NF_LN_FWD(N)                                                                          \
+    case N:                                                                                   \
+        if (delta != nullptr)                                                                 \
+            hipLaunchKernelGGL((ln_fwd_kernel<true, N>), grid, block, 0, s, xi, dl, xo, ga, be, yo, \
+                               mean, rstd, R, C, eps);                                        \
+        else                                                                                  \
+            hipLaunchKernelGGL((ln_fwd_kernel<false, N>), grid, block, 0, s, xi, nullptr, nullptr, \
+                               ga, be, yo, mean, rstd, R, C, eps);                            \
+        break;
+    switch ((C + 255) / 256) {
+        NF_LN_FWD(1) NF_LN_FWD(2) NF_LN_FWD(3) NF_LN_FWD(4)
+        NF_LN_FWD(5) NF_LN_FWD(6) NF_LN_FWD(7) NF_LN_FWD(8)
+    default: return -1;
+    }
+#undef NF_LN_FWD
     return NF_NN_OK();
 }
 
+// row chunks of the column-sum pass
 int nf_ln_bwd_blocks(int R) {
-    const int b = (R + 3) / 4;
-    return b < 256 ? b : 256;
+    (void)R;
+    return 64;
 }
 
 // partial: nf_ln_bwd_blocks(R) * 3 * C floats of workspace.  dres may be null;
-// dx may alias dres or dy.  dxsum (may be null) receives the column sums of dx.
+// dx may alias dres (not dy).  dxsum (may be null) receives the column sums of dx.
 int nf_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
               const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
               void* dxsum, float* partial, int R, int C, hipStream_t s) {
-    if (R <= 0 || C <= 0 || C % 4 != 0 || C > kLnMaxChunks * 256) return -1;
-    if (!aligned(dy, 8) || !aligned(x, 8) || !aligned(dx, 8) || !aligned(gamma, 8)) return -2;
+    if (R <= 0 || C <= 0 || C % 8 != 0 || C > kLnMaxChunks * 256) return -1;
+    if (!aligned(dy, 16) || !aligned(x, 16) || !aligned(dx, 16) || !aligned(gamma, 8)) return -2;
     if (dres != nullptr && !aligned(dres, 8)) return -2;
+    const bf16* dyp = static_cast<const bf16*>(dy);
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* ga = static_cast<const bf16*>(gamma);
+    const bf16* dr = static_cast<const bf16*>(dres);
+    bf16* dxp = static_cast<bf16*>(dx);
+    const dim3 grid((R + 3) / 4), block(256);
+#define NF_LN_BWD(N)                                                                          \
+    case N:                                                                                   \
+        if (dres != nullptr)                                                                  \
+            hipLaunchKernelGGL((ln_bwd_dx_kernel<true, N>), grid, block, 0, s, dyp, xp, ga, mean, \
+                               rstd, dr, dxp, R, C);                                          \
+        else                                                                                  \
+            hipLaunchKernelGGL((ln_bwd_dx_kernel<false, N>), grid, block, 0, s, dyp, xp, ga, mean, \
+                               rstd, nullptr, dxp, R, C);                                     \
+        break;
+    switch ((C + 255) / 256) {
+        NF_LN_BWD(1) NF_LN_BWD(2) NF_LN_BWD(3) NF_LN_BWD(4)
+        NF_LN_BWD(5) NF_LN_BWD(6) NF_LN_BWD(7) NF_LN_BWD(8)
+    default: return -1;
+    }
+#undef NF_LN_BWD
     const int nb = nf_ln_bwd_blocks(R);
-    const int rpb = (R + nb - 1) / nb;
-    const size_t lds = static_cast<size_t>(12) * C * sizeof(float);
-    static const hipError_t a1 = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(ln_bwd_kernel<true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 12 * kLnMaxChunks * 256 * 4);
-    static const hipError_t a2 = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(ln_bwd_kernel<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 12 * kLnMaxChunks * 256 * 4);
-    if (a1 != hipSuccess || a2 != hipSuccess) return -20;
-    if (dres != nullptr)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nb), dim3(256), lds, s,
-                           static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
-                           static_cast<const bf16*>(gamma), mean, rstd,
-                           static_cast<const bf16*>(dres), static_cast<bf16*>(dx), partial, R, C,
-                           rpb);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nb), dim3(256), lds, s,
-                           static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
-                           static_cast<const bf16*>(gamma), mean, rstd, nullptr,
-                           static_cast<bf16*>(dx), partial, R, C, rpb);
+    const int rows = (R + nb - 1) / nb;
+    hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3((C + 511) / 512, nb), dim3(256), 0, s, dyp, xp,
+                       static_cast<const bf16*>(dx), mean, rstd, partial, R, C, rows);
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * C + 63) / 64), dim3(256), 0, s, partial,
                        static_cast<bf16*>(dgamma), static_cast<bf16*>(dbeta),
                        static_cast<bf16*>(dxsum), nb, C);

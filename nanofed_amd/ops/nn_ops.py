@@ -170,9 +170,11 @@ def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.T
         out = out + dres.float()
     dgamma.copy_((d * xh).sum(0).to(torch.bfloat16))
     dbeta.copy_(d.sum(0).to(torch.bfloat16))
+    rounded = out.to(torch.bfloat16)
     if dxsum is not None:
-        dxsum.copy_(out.sum(0).to(torch.bfloat16))
-    dx.copy_(out.to(torch.bfloat16))
+        # column sums of the gradient as it is handed on (bf16), like the kernel
+        dxsum.copy_(rounded.float().sum(0).to(torch.bfloat16))
+    dx.copy_(rounded)
 
 
 def gelu_fwd(x: torch.Tensor, y: torch.Tensor) -> None:
