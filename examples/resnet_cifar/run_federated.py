@@ -1,0 +1,55 @@
+"""Federated ResNet-18 on CIFAR-10-shaped data (synthetic by default).
+
+    python examples/resnet_cifar/run_federated.py --clients 8 --rounds 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29521 examples/resnet_cifar/run_federated.py --clients 8
+
+Convolutions run through MIOpen on channels-last arena weights; BatchNorm, the
+residual add and the ReLU are one fused HIP kernel; each client's whole step is
+replayed from a hipGraph; FedAvg is one fused reduce (+ an RCCL all-reduce when
+several GPUs take part).  BatchNorm running statistics are averaged with the
+weights, integer buffers stay out of the float average.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from nanofed_amd.engine import EngineConfig, FederatedEngine  # noqa: E402
+from nanofed_amd.parallel import Communicator  # noqa: E402
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clients", type=int, default=8)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--samples-per-client", type=int, default=1024)
+    ap.add_argument("--local-epochs", type=int, default=1)
+    ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--alpha", type=float, default=0.0, help="> 0: Dirichlet(alpha) non-IID shards")
+    ap.add_argument("--base-dir", default=None)
+    args = ap.parse_args()
+    comm = Communicator.from_env()
+    cfg = EngineConfig(
+        model="resnet18", dataset="synthetic_cifar10", num_clients=args.clients,
+        samples_per_client=args.samples_per_client, batch_size=64,
+        local_epochs=args.local_epochs, learning_rate=args.lr, eval_samples=2000,
+        partition="dirichlet" if args.alpha > 0 else "iid", dirichlet_alpha=args.alpha or 0.1,
+    )
+    engine = FederatedEngine(cfg, comm=comm, base_dir=args.base_dir)
+    for report in engine.run(args.rounds):
+        if comm.is_root:
+            print(json.dumps({"round": report.round_id, "status": report.status,
+                              **report.agg_metrics, "wall_s": round(report.wall_s, 3)}))
+    if comm.is_root:
+        print(json.dumps({"eval": engine.evaluate()}))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
