@@ -48,6 +48,8 @@ def main() -> int:
     from nanofed_amd.engine import EngineConfig, FederatedEngine
     from nanofed_amd.parallel import Communicator
 
+    # keep the collective library quiet on stdout (rank 0 prints exactly one JSON line)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
@@ -89,7 +91,7 @@ def main() -> int:
         rounds_per_s = args.steps / elapsed
         last = reports[-1] if reports else None
         line = {
-            "metric": "federated rounds/sec (MNIST-CNN FedAvg, 8 clients)",
+            "metric": f"federated rounds/sec (MNIST-CNN FedAvg, {args.clients} clients)",
             "value": rounds_per_s,
             "unit": "rounds/s",
             "n_gpus": comm.world_size,
