@@ -28,6 +28,17 @@ import torch
 BASELINE_ROUNDS_PER_S = 1.0 / 53.48
 
 
+def _restore_stdout(saved_fd: int) -> None:
+    import ctypes
+
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)  # whatever C code still holds in its stdio buffers
+    except OSError:
+        pass
+    os.dup2(saved_fd, 1)
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,6 +58,13 @@ def main() -> int:
 
     from nanofed_amd.engine import EngineConfig, FederatedEngine
     from nanofed_amd.parallel import Communicator
+
+    # Libraries print to stdout on their own (RCCL's version banner, gloo's
+    # connection notes).  Until the result line is due, file descriptor 1 points at
+    # stderr, so stdout carries exactly one JSON line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     # keep the collective library quiet on stdout (rank 0 prints exactly one JSON line)
     os.environ.setdefault("NCCL_DEBUG", "WARN")
@@ -121,7 +139,9 @@ def main() -> int:
                 "parallelism": f"fed{args.clients}/gpu{comm.world_size}",
             },
         }
+        _restore_stdout(real_stdout)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     comm.close()
     return 0
 
