@@ -566,12 +566,11 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-fc1_wgrad_kernel(MnistCtx c, int step) {
+__device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int tile, int g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_dh = smem;                    // [64 b][128 j]
     char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
-    const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31;
     if (c.fuse_sgd && c.nvalid[g * c.nvalid_stride + step] == 0) return;
     const bf16* dh = c.dh1 + static_cast<long>(g) * c.B * 128;
@@ -620,6 +619,11 @@ fc1_wgrad_kernel(MnistCtx c, int step) {
     }
 }
 
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+fc1_wgrad_kernel(MnistCtx c, int step) {
+    fc1_wgrad_body(c, step, blockIdx.x, blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------
 // d(conv2 out) at pixel (oy, ox), channels part*8..+7, from the pooled gradient
 // and the arg-max code: the value belongs to the window position that won.
@@ -653,15 +657,14 @@ __device__ __forceinline__ int dg_swz(int pr, int pc, int part) {
     return (pr * kDgPatchCols + pc) * 128 + ((part ^ (((pc >> 1) + 5 * pr) & 7)) << 4);
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-conv2_dgrad_kernel(MnistCtx c, int idx_off) {
+__device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off, int bx, int g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);       // normalised input image
     int* soff = reinterpret_cast<int*>(xs + 784);                     // a1 pixel -> offset in xs
     unsigned* smask = reinterpret_cast<unsigned*>(soff + kDgPixPad);  // a1 pixel -> ReLU bits
     float* red = reinterpret_cast<float*>(smask + kDgPixPad);
-    const int b = blockIdx.x / c.split, g = blockIdx.y, tid = threadIdx.x;
-    const int chunk0 = c.split == 1 ? 0 : blockIdx.x - b * c.split;
+    const int b = bx / c.split, tid = threadIdx.x;
+    const int chunk0 = c.split == 1 ? 0 : bx - b * c.split;
     const int chunk1 = c.split == 1 ? 3 : chunk0 + 1;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const long img = static_cast<long>(g) * c.B + b;
@@ -797,6 +800,25 @@ conv2_dgrad_kernel(MnistCtx c, int idx_off) {
         __syncthreads();
         if (tid == 0) c.dp_normsq[img * 4 + 1] = red[0] + red[1] + red[2] + red[3];
     }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv2_dgrad_kernel(MnistCtx c, int idx_off) {
+    conv2_dgrad_body(c, idx_off, blockIdx.x, blockIdx.y);
+}
+
+// conv2_dgrad and fc1_wgrad in one launch (they are independent once fc1_dgrad
+// is done).  With one or two clients on the GPU neither fills the chip on its
+// own, so the workgroups of both run side by side; the first n_dg indices of
+// blockIdx.x are conv2_dgrad's.
+constexpr int kPairLds = kDgLds > 2 * 64 * kTrPitch128 ? kDgLds : 2 * 64 * kTrPitch128;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bwd_pair_kernel(MnistCtx c, int idx_off, int step, int n_dg) {
+    if (static_cast<int>(blockIdx.x) < n_dg)
+        conv2_dgrad_body(c, idx_off, blockIdx.x, blockIdx.y);
+    else
+        fc1_wgrad_body(c, step, blockIdx.x - n_dg, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -1140,7 +1162,8 @@ int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
 
 // stage: 0 conv1_fwd, 1 conv2_fwd, 2 fc1_fwd, 3 head, 4 fc1_dgrad, 5 fc1_wgrad,
 //        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only,
-//        11 dp_scale, 12 finalize + SGD of everything but fc1.weight (fuse_sgd only)
+//        11 dp_scale, 12 finalize + SGD of everything but fc1.weight (fuse_sgd only),
+//        13 conv2_dgrad + fc1_wgrad in one launch
 int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
     const int rc = check_ctx(c);
     if (rc) return rc;
@@ -1163,6 +1186,14 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, split_grid, dim3(256), kDgLds, s, *c, idx_off); break;
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
     case 8: hipLaunchKernelGGL(finalize_kernel<false>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step); break;
+    case 13: {
+        // conv2_dgrad + fc1_wgrad side by side (plain SGD only)
+        if (c->dp_pass != 0) return -12;
+        const int n_dg = c->B * c->split;
+        hipLaunchKernelGGL(bwd_pair_kernel, dim3(n_dg + kFc1Tiles, c->G), dim3(256), kPairLds, s,
+                           *c, idx_off, step, n_dg);
+        break;
+    }
     case 12:
         if (!c->fuse_sgd || c->dp_pass != 0) return -12;
         hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step);
@@ -1186,6 +1217,15 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
 // gradient.  Noise is added by sgd_pack.
 int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
     if (c->dp_pass == 0) {
+        if (c->fuse_sgd && c->G <= 2) {
+            // few clients: the two independent backward kernels share one launch
+            static const int few[] = {0, 1, 2, 3, 4, 13, 7, 12};
+            for (int stage : few) {
+                const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
+                if (rc) return rc;
+            }
+            return 0;
+        }
         // with fc1.weight updated inside fc1_wgrad, one launch finishes the step
         const int last = c->fuse_sgd ? 7 : 9;
         for (int stage = 0; stage <= last; ++stage) {

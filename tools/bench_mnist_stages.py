@@ -40,7 +40,7 @@ def main() -> None:
     buf.train_steps(0, 2)  # realistic activations / gradients in every buffer
     torch.cuda.synchronize()
     out = {}
-    skip = ("pack", "finalize_sgd") if args.dp else ("pack", "dp_scale")
+    skip = ("pack", "finalize_sgd", "bwd_pair") if args.dp else ("pack", "dp_scale")
     order = [n for n in STAGES if n not in skip]
     if args.only:
         order = args.only.split(",")
