@@ -23,6 +23,7 @@ describes that with arena storage permutations, so ``state_dict`` /
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
 
 import torch
@@ -163,14 +164,28 @@ class NativeBuffers:
         self.dp2 = z(G, B, 144, 64, dtype=torch.bfloat16)
         self.a1mask = z(G, B, 676, dtype=torch.int32)
         self.conv1_part = z(G, 3 * B, 320)
-        # DP-SGD measures per-sample norms from per-image tiles: one image per workgroup
-        # few clients on the GPU: cut the conv2 kernels into one band per workgroup
-        # (3x the workgroups, 1/3 the work each) so the chip is not left idle
-        few = G <= 2 and dp is None
+        # Kernel geometry by the number of clients on the GPU (measured with
+        # tools/bench_mnist_stages.py): with few clients the conv2 kernels are cut into
+        # one band per workgroup (3x the workgroups, 1/3 the work each), conv1 into 2-4
+        # pieces per image and conv2_wgrad into more, smaller workgroups, so the chip
+        # is not left idle.  DP-SGD measures per-sample norms from per-image tiles:
+        # one image per workgroup there.
+        if dp is not None:
+            split, wpc, conv1_split = 1, B, 1
+        elif G <= 1:
+            split, wpc, conv1_split = 3, 3 * B, 4
+        elif G == 2:
+            split, wpc, conv1_split = 3, 96, 4
+        elif G <= 4:
+            split, wpc, conv1_split = 3, 64, 2
+        else:
+            split, wpc, conv1_split = 1, CONV2_WG_PER_CLIENT, 1
         if cfg is not None and cfg.conv_split in (1, 3) and dp is None:
-            few = cfg.conv_split == 3
-        split = 3 if few else 1
-        wpc = B if dp is not None else (3 * B if few else CONV2_WG_PER_CLIENT)
+            split = cfg.conv_split
+        # tuning override: NANOFED_MNIST_GEOMETRY="split,wpc,conv1_split"
+        geometry = os.environ.get("NANOFED_MNIST_GEOMETRY")
+        if geometry and dp is None:
+            split, wpc, conv1_split = (int(v) for v in geometry.split(","))
         self.conv2_part = z(G, wpc, 18432)
         self.dp_normsq = z(G, B, 4)
         self.dp_rowscale = z(G, B)
@@ -185,7 +200,7 @@ class NativeBuffers:
         c = MnistCtx()
         c.G, c.B, c.S, c.WPC = G, B, FC1_SPLITS, wpc
         c.split = split
-        c.conv1_split = 4 if G <= 2 else 1
+        c.conv1_split = conv1_split
         c.train = 1 if train else 0
         c.client_base = client_base
         c.images = self.images.data_ptr()

@@ -35,7 +35,11 @@ comm.close()
 """
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
+GEOMETRY = "1,32,1"  # the same kernel geometry whatever the number of clients per rank
+
+
+def test_two_ranks_equal_one_rank(tmp_path, monkeypatch):
+    monkeypatch.setenv("NANOFED_MNIST_GEOMETRY", GEOMETRY)
     out = tmp_path / "dist.pt"
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, cfg=CFG, out=str(out)))
@@ -43,7 +47,7 @@ def test_two_ranks_equal_one_rank(tmp_path):
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
         capture_output=True, text=True, timeout=280,
-        env=dict(os.environ, MASTER_ADDR="127.0.0.1"),
+        env=dict(os.environ, MASTER_ADDR="127.0.0.1", NANOFED_MNIST_GEOMETRY=GEOMETRY),
     )
     assert proc.returncode == 0, proc.stderr[-3000:]
     dist = torch.load(out, weights_only=True)
@@ -51,8 +55,8 @@ def test_two_ranks_equal_one_rank(tmp_path):
     single = FederatedEngine(EngineConfig(**CFG), comm=Communicator(device=torch.device("cuda", 0)))
     reps = single.run(1)
     assert dist["weights"] == pytest.approx([320 / 896, 256 / 896, 192 / 896, 128 / 896])
-    # same kernel geometry on both sides (conv_split pinned): every client trains
-    # bit-identically; only the FedAvg sum is associated differently
+    # same kernel geometry on both sides (pinned through the environment): every
+    # client trains bit-identically; only the FedAvg sum is associated differently
     # (one round: a second round would start every client from a model that differs
     # in the last bit, and early SGD at lr 0.1 amplifies that)
     torch.testing.assert_close(dist["flat"], single.global_arena.data.cpu(), rtol=1e-5, atol=1e-6)
