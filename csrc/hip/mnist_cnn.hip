@@ -625,25 +625,33 @@ fc1_wgrad_kernel(MnistCtx c, int step) {
 }
 
 // ---------------------------------------------------------------------------
-// d(conv2 out) at pixel (oy, ox), channels part*8..+7, from the pooled gradient
-// and the arg-max code: the value belongs to the window position that won.
-__device__ __forceinline__ uint4 expand_da2(const bf16* dp2img, const uint8_t* maskimg,
-                                            int oy, int ox, int part) {
-    const int pooled = (oy >> 1) * 12 + (ox >> 1);
-    const unsigned q = ((oy & 1) << 1) | (ox & 1);
-    const uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
-    const uint2 m = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);
-    unsigned w[4] = {v.x, v.y, v.z, v.w};
-    const unsigned mm[2] = {m.x, m.y};
+// d(conv2 out) from the pooled gradient and the arg-max codes: the value of a
+// channel belongs to the window position that won the max.
+// The 2x2 window of one pooled pixel, 8 channels: position q (= 2 * dy + dx)
+// receives the pooled gradient of the channels whose arg-max code is q, zero
+// for the others.  One load of gradient and codes serves all four positions.
+struct PoolWindow {
+    unsigned w[4], h0[4], h1[4];  // h*: one-hot of the winning position, low / high channel of a word
+    __device__ __forceinline__ PoolWindow(uint4 v, uint2 m) {
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        const unsigned mm[2] = {m.x, m.y};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned pair = mm[i >> 1] >> (16 * (i & 1));
-        const unsigned k0 = ((pair & 3u) == q) ? 0x0000FFFFu : 0u;
-        const unsigned k1 = (((pair >> 8) & 3u) == q) ? 0xFFFF0000u : 0u;
-        w[i] &= (k0 | k1);
+        for (int k = 0; k < 4; ++k) {
+            const unsigned pair = mm[k >> 1] >> (16 * (k & 1));
+            h0[k] = 1u << (pair & 3u);
+            h1[k] = 1u << ((pair >> 8) & 3u);
+        }
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
+    __device__ __forceinline__ uint4 at(int q) const {
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lo = 0u - ((h0[k] >> q) & 1u), hi = 0u - ((h1[k] >> q) & 1u);
+            o[k] = w[k] & ((lo & 0x0000FFFFu) | (hi & 0xFFFF0000u));
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+};
 
 constexpr int kDgPatchRows = 13, kDgPatchCols = 28;
 constexpr int kDgPatchBytes = kDgPatchRows * kDgPatchCols * 128;  // 46592
@@ -725,20 +733,33 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
         const int oy_base = ymin - 2;
         const int nrows = ymax - ymin + 3;
         __syncthreads();
-        // up to 12 pieces per thread; loads are unconditional (clamped
-        // coordinates) so that the unrolled iterations keep several in flight
-        const int npieces = nrows * kDgPatchCols * 8;
+        // One item = one pooled pixel x 8 channels: a single load of the pooled
+        // gradient and the arg-max codes feeds the four positions of its 2x2 window.
+        // Pooled rows/columns one step outside the image produce the zero halo.
+        // Loads are unconditional (clamped coordinates) so that the unrolled
+        // iterations keep several in flight.
+        const int py_base = ((oy_base + 2) >> 1) - 1;  // floor(oy_base / 2), oy_base >= -2
+        const int nprow = ((oy_base + nrows + 1) >> 1) - py_base;
+        const int nitems = nprow * 14 * 8;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int p = tid + i * 256;
-            const int pcl = min(p, npieces - 1);
-            const int pi = pcl >> 3, part = pcl & 7;
-            const int pr = pi / kDgPatchCols, pc = pi - pr * kDgPatchCols;
-            const int oy = oy_base + pr, ox = pc - 2;
-            const bool inside = oy >= 0 && oy < 24 && ox >= 0 && ox < 24;
-            uint4 v = expand_da2(dp2img, maskimg, min(max(oy, 0), 23), min(max(ox, 0), 23), part);
-            if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
-            if (p < npieces) *reinterpret_cast<uint4*>(smem + dg_swz(pr, pc, part)) = v;
+        for (int i = 0; i < 4; ++i) {
+            const int it = tid + i * 256;
+            const int itc = min(it, nitems - 1);
+            const int part = itc & 7, pi = itc >> 3;
+            const int prow = pi / 14, pcol = pi - prow * 14;
+            const int py = py_base + prow, px = pcol - 1;
+            const bool inside = py >= 0 && py < 12 && px >= 0 && px < 12;
+            const int pooled = min(max(py, 0), 11) * 12 + min(max(px, 0), 11);
+            const uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
+            const uint2 m = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);
+            const PoolWindow win(v, m);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pr = 2 * py + (q >> 1) - oy_base, pc = 2 * px + (q & 1) + 2;
+                const uint4 o = inside ? win.at(q) : make_uint4(0u, 0u, 0u, 0u);
+                if (it < nitems && pr >= 0 && pr < nrows)
+                    *reinterpret_cast<uint4*>(smem + dg_swz(pr, pc, part)) = o;
+            }
         }
         __syncthreads();
 
@@ -842,44 +863,44 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
     const int lq = li >> 2;
     const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
 
-    // fixed piece -> (pixel, part) assignment of this thread: pieces tid + 384 i.
-    // Named registers for the prefetched pieces (an indexed array lands in scratch).
+    // A band of 8 output rows is 4 x 12 pooled pixels x 8 channel groups = 384
+    // items, one per thread: the thread loads its 16 B of pooled gradient and 8 B
+    // of arg-max codes (contiguous over the workgroup) and writes the four
+    // positions of the 2x2 window.  The loads for the next band are issued before
+    // the MFMA loop of the current one and held in named registers.
+    const int wpi = tid >> 3, wprow = wpi / 12, wpcol = wpi - wprow * 12;
+    char* const da_dst = s_da + (2 * wprow * 24 + 2 * wpcol) * kWgDaPitch + (tid & 7) * 16;
     const int q2 = min(tid + 768, 1039);
     const bool has2 = tid + 768 < 1040;
-    uint4 pv0, pv1, pv2, pv3, pa0, pa1, pa2;
-#define NF_WG_DA(i_, dst_)                                                              \
-    {                                                                                   \
-        const int p_ = tid + (i_) * 384, px_ = p_ >> 3;                                 \
-        dst_ = expand_da2(dp2img_, maskimg_, band_ * 8 + px_ / 24, px_ % 24, p_ & 7);   \
-    }
+    uint4 pv, pa0, pa1, pa2;
+    uint2 pm;
 #define NF_WG_ISSUE(it_)                                                                \
     {                                                                                   \
         const int gi_ = it0 + (it_);                                                    \
         const int im_ = gi_ / 3, band_ = gi_ - im_ * 3;                                 \
         const long img_ = static_cast<long>(g) * c.B + im_;                             \
-        const bf16* dp2img_ = c.dp2 + img_ * kP2Pix * kC2;                              \
-        const uint8_t* maskimg_ = c.pmask + img_ * kP2Pix * kC2;                        \
-        NF_WG_DA(0, pv0) NF_WG_DA(1, pv1) NF_WG_DA(2, pv2) NF_WG_DA(3, pv3)             \
+        const long off_ = (img_ * kP2Pix + band_ * 48) * kC2 + tid * 8;                 \
+        pv = *reinterpret_cast<const uint4*>(c.dp2 + off_);                             \
+        pm = *reinterpret_cast<const uint2*>(c.pmask + off_);                           \
         const uint4* sa1_ = reinterpret_cast<const uint4*>(                             \
             c.a1 + (img_ * kA1Pix + band_ * 8 * 26) * kA1C);                            \
         pa0 = sa1_[tid]; pa1 = sa1_[tid + 384]; pa2 = sa1_[q2];                         \
     }
-#define NF_WG_DST(i_) (s_da + ((tid + (i_) * 384) >> 3) * kWgDaPitch + ((tid + (i_) * 384) & 7) * 16)
     NF_WG_ISSUE(0)
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
-        *reinterpret_cast<uint4*>(NF_WG_DST(0)) = pv0;
-        *reinterpret_cast<uint4*>(NF_WG_DST(1)) = pv1;
-        *reinterpret_cast<uint4*>(NF_WG_DST(2)) = pv2;
-        *reinterpret_cast<uint4*>(NF_WG_DST(3)) = pv3;
+        {
+            const PoolWindow win(pv, pm);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(da_dst + ((q >> 1) * 24 + (q & 1)) * kWgDaPitch) = win.at(q);
+        }
         *reinterpret_cast<uint4*>(s_a1 + tid * 16) = pa0;
         *reinterpret_cast<uint4*>(s_a1 + (tid + 384) * 16) = pa1;
         if (has2) *reinterpret_cast<uint4*>(s_a1 + q2 * 16) = pa2;
         if (it + 1 < nit) NF_WG_ISSUE(it + 1)
         __syncthreads();
-#undef NF_WG_DA
 #undef NF_WG_ISSUE
-#undef NF_WG_DST
 #pragma unroll 2
         for (int ks = 0; ks < 12; ++ks) {
             const bf16x8 Afr = load_tr_frag(s_da, kWgDaPitch, ks * 16, ocb * 32, lane);
