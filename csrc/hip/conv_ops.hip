@@ -1,0 +1,452 @@
+// 3x3 convolution, stride 1, zero padding 1, for channels-last bf16 activations
+// on gfx950: forward (which also serves the data gradient, on flipped weights)
+// and the weight gradient, as implicit GEMMs on the 32x32x16 bf16 MFMA.
+//
+// Layouts: activations [B][H][W][C] (channels-last), weights [Cout][3][3][Cin]
+// (the channels-last storage of a [Cout, Cin, 3, 3] tensor).  H and W are powers
+// of two, channel counts multiples of 64.
+//
+// Forward.  A workgroup of four waves computes a tile of TP consecutive pixels
+// (raster order over image, row, column) by 64 output channels.  The pixels of
+// a tile form NI bands of RI image rows; the bands are staged in LDS with a halo
+// of one pixel, so the nine taps are nine shifted reads of one patch.  The
+// reduction runs over chunks of 32 input channels: per chunk the patch and the
+// [64 oc][9 taps][32 ic] weight slice are staged (pitch 80 bytes: 16-byte
+// row-major fragment reads without bank conflicts), which makes 18 MFMA k-steps.
+// Waves are arranged PXW x KSW: PXW pixel groups of 64 pixels, KSW waves sharing
+// the k-steps of one pixel group; the partial accumulators of a pixel group are
+// summed through LDS at the end.  Deep layers (few pixels, many channels) use
+// 1 x 4 so that a layer still makes >= 128 workgroups; wide layers 2 x 2.
+//
+// Weight gradient.  dW[oc][tap][ic] = sum over pixels dY[px][oc] * X[px + tap][ic]:
+// both operands have the reduction index (pixels) as the slow dimension in
+// memory, so both fragments come from transposing LDS reads.  A workgroup owns a
+// 64 oc x 64 ic tile for a range of pixels; each wave accumulates a 32 x 32
+// sub-tile for all nine taps (144 accumulator registers; one dY fragment feeds
+// nine MFMAs).  Pixel ranges write fp32 partial slabs that a second kernel sums
+// in a fixed order (no atomics: results do not depend on scheduling).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nf_device.h"
+
+using namespace nfd;
+
+namespace {
+
+constexpr int kChunk = 32;              // input channels per staging step (forward)
+constexpr int kPitch = kChunk * 2 + 16; // 80 bytes per staged pixel / weight row
+constexpr int kBRows = 64 * 9;
+constexpr int kBBytes = kBRows * kPitch;  // 46080
+constexpr int kMaxAPieces = 5;            // ceil(max patch pixels * 4 / 256)
+constexpr int kMaxPatchFwd = kMaxAPieces * 64;
+constexpr int kRedBytes = 4 * 4 * 16 * 64 * 4;  // accumulators of four waves
+
+struct ConvGeo {
+    int H, W, logH, logW;  // image size
+    int RI, logRI;         // image rows per band
+    int NI;                // bands per tile
+    int np;                // patch pixels of a tile: NI * (RI + 2) * (W + 2)
+    int Cin, Cout;
+};
+
+// Patch pixel pp of the tile whose first image row (index over b * H + y) is row0:
+// element offset of its first channel in the activation tensor, or -1 in the halo
+// outside the image.
+__device__ __forceinline__ int patch_source(const ConvGeo& g, int row0, int pp) {
+    const int PW = g.W + 2, PR = g.RI + 2;
+    const int band = pp / (PR * PW);
+    const int rem = pp - band * PR * PW;
+    const int pr = rem / PW, pc = rem - pr * PW;
+    const int grow = row0 + band * g.RI;
+    const int img = grow >> g.logH, y0 = grow & (g.H - 1);
+    const int yy = y0 + pr - 1, xx = pc - 1;
+    if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) return -1;
+    return ((img * g.H + yy) * g.W + xx) * g.Cin;
+}
+
+// Patch index (without tap shift) of pixel m of a tile.
+__device__ __forceinline__ int patch_index(const ConvGeo& g, int m) {
+    const int band = m >> (g.logRI + g.logW);
+    const int r = (m >> g.logW) & (g.RI - 1);
+    const int xx = m & (g.W - 1);
+    return (band * (g.RI + 2) + r) * (g.W + 2) + xx;
+}
+
+template <int PXW, int KSW>
+__global__ void __launch_bounds__(256)
+conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
+                   ConvGeo g) {
+    static_assert(PXW * KSW == 4, "four waves");
+    constexpr int TP = 64 * PXW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_b = smem;            // [64 oc * 9 taps][32 ic], pitch 80
+    char* s_a = smem + kBBytes;  // [patch pixel][32 ic], pitch 80
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pw = wave % PXW, kw = wave / PXW;
+    const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
+    const int PW = g.W + 2;
+    const int row0 = (tile * TP) >> g.logW;
+
+    // staging plan of the activation patch: pieces tid + 256 i, 16 bytes each
+    int a_src[kMaxAPieces], a_dst[kMaxAPieces];
+#pragma unroll
+    for (int i = 0; i < kMaxAPieces; ++i) {
+        const int q = tid + i * 256, pp = q >> 2, p = q & 3;
+        if (pp < g.np) {
+            const int src = patch_source(g, row0, pp);
+            a_src[i] = src < 0 ? -1 : src + p * 8;
+            a_dst[i] = pp * kPitch + p * 16;
+        } else {
+            a_src[i] = -1;
+            a_dst[i] = -1;
+        }
+    }
+    // fragment rows of this lane
+    int a_row[2], b_row[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+        a_row[mb] = patch_index(g, pw * 64 + mb * 32 + (lane & 31)) * kPitch + (lane >> 5) * 16;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+        b_row[nb] = (nb * 32 + (lane & 31)) * 9 * kPitch + (lane >> 5) * 16;
+
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    const int s_lo = (18 * kw) / KSW, s_hi = (18 * (kw + 1)) / KSW;
+    const int nchunks = g.Cin / kChunk;
+    const bf16* wsrc = w + static_cast<long>(oc0) * 9 * g.Cin;
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int q = tid + i * 256, row = q >> 2, p = q & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * g.Cin +
+                                                            c * kChunk + p * 8);
+            *reinterpret_cast<uint4*>(s_b + row * kPitch + p * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxAPieces; ++i) {
+            if (a_dst[i] >= 0) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (a_src[i] >= 0) v = *reinterpret_cast<const uint4*>(x + a_src[i] + c * kChunk);
+                *reinterpret_cast<uint4*>(s_a + a_dst[i]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = s_lo; s < s_hi; ++s) {
+            const int tap = s >> 1, sub = s & 1;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int aoff = (ky * PW + kx) * kPitch + sub * 32;
+            const int boff = tap * kPitch + sub * 32;
+            const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(s_a + a_row[0] + aoff);
+            const bf16x8 A1 = *reinterpret_cast<const bf16x8*>(s_a + a_row[1] + aoff);
+            const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(s_b + b_row[0] + boff);
+            const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(s_b + b_row[1] + boff);
+            acc[0][0] = mfma32(A0, B0, acc[0][0]);
+            acc[0][1] = mfma32(A0, B1, acc[0][1]);
+            acc[1][0] = mfma32(A1, B0, acc[1][0]);
+            acc[1][1] = mfma32(A1, B1, acc[1][1]);
+        }
+    }
+
+    // sum the k-split partial accumulators of each pixel group, write bf16
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][block mb*2+nb][reg][lane]
+    if constexpr (KSW > 1) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[((wave * 4 + mb * 2 + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+        __syncthreads();
+    }
+    constexpr int kBlocksPerWave = 4 / KSW;
+#pragma unroll
+    for (int j = 0; j < kBlocksPerWave; ++j) {
+        const int blk = kw * kBlocksPerWave + j, mb = blk >> 1, nb = blk & 1;
+        const long pix0 = static_cast<long>(tile) * TP + pw * 64 + mb * 32;
+        bf16* dst = y + pix0 * g.Cout + oc0 + nb * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v;
+            if constexpr (KSW > 1) {
+                v = 0.f;
+#pragma unroll
+                for (int k2 = 0; k2 < KSW; ++k2)
+                    v += red[(((k2 * PXW + pw) * 4 + blk) * 16 + r) * 64 + lane];
+            } else {
+                v = acc[j >> 1][j & 1][r];
+            }
+            dst[static_cast<long>(acc_row(r, lane)) * g.Cout] = f2bf(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weights [Cout][9][Cin] -> [Cin][9][Cout] with the taps reversed: the forward
+// kernel on these computes the data gradient.
+__global__ void __launch_bounds__(256)
+flip_weights_kernel(const bf16* __restrict__ w, bf16* __restrict__ wt, int Cin, int Cout) {
+    // one workgroup per (64 oc, 64 ic, tap): transpose through LDS
+    __shared__ bf16 t[64][66];
+    const int tap = blockIdx.x, oc0 = blockIdx.y * 64, ic0 = blockIdx.z * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * 256, o = e >> 6, c = e & 63;
+        t[o][c] = w[(static_cast<long>(oc0 + o) * 9 + tap) * Cin + ic0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * 256, c = e >> 6, o = e & 63;
+        wt[(static_cast<long>(ic0 + c) * 9 + (8 - tap)) * Cout + oc0 + o] = t[o][c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kWgTP = 128;       // pixels per iteration
+constexpr int kWgPitch = 160;    // 64 channels + 32 bytes (transposing reads)
+constexpr int kWgDyBytes = kWgTP * kWgPitch;  // 20480
+constexpr int kWgMaxPatch = 288;
+constexpr int kWgLds = kWgDyBytes + kWgMaxPatch * kWgPitch;  // 66560
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                     float* __restrict__ part, ConvGeo g, int nit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_dy = smem;               // [128 px][64 oc], pitch 160
+    char* s_x = smem + kWgDyBytes;   // [patch pixel][64 ic], pitch 160
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ob = wave & 1, ib = wave >> 1, h = lane >> 5;
+    const int ict = g.Cin >> 6;
+    const int oc0 = (blockIdx.y / ict) * 64, ic0 = (blockIdx.y % ict) * 64;
+    const int PW = g.W + 2, PR = g.RI + 2;
+
+    // patch staging plan, tile independent part: pieces tid + 256 i
+    // (band, row - 1, column - 1) packed, or -1 past the patch
+    int plan[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int q = tid + i * 256, pp = q >> 3;
+        if (pp < g.np) {
+            const int band = pp / (PR * PW);
+            const int rem = pp - band * PR * PW;
+            const int pr = rem / PW, pc = rem - pr * PW;
+            plan[i] = (band << 16) | (pr << 8) | pc;
+        } else {
+            plan[i] = -1;
+        }
+    }
+    // transposed-read lane geometry (see nfd::load_tr_frag)
+    const int li = lane & 15, lq = li >> 2;
+    const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    const char* xb = s_x + (ib * 32) * 2 + lcol;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x16{0};
+
+    for (int it = 0; it < nit; ++it) {
+        const int tile = blockIdx.x * nit + it;
+        const int row0 = (tile * kWgTP) >> g.logW;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256, px = q >> 3, p = q & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(
+                dy + (static_cast<long>(tile) * kWgTP + px) * g.Cout + oc0 + p * 8);
+            *reinterpret_cast<uint4*>(s_dy + px * kWgPitch + p * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (plan[i] >= 0) {
+                const int q = tid + i * 256, pp = q >> 3, p = q & 7;
+                const int band = plan[i] >> 16, pr = (plan[i] >> 8) & 255, pc = plan[i] & 255;
+                const int grow = row0 + band * g.RI;
+                const int img = grow >> g.logH, y0 = grow & (g.H - 1);
+                const int yy = y0 + pr - 1, xx = pc - 1;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+                    v = *reinterpret_cast<const uint4*>(
+                        x + static_cast<long>((img * g.H + yy) * g.W + xx) * g.Cin + ic0 + p * 8);
+                *reinterpret_cast<uint4*>(s_x + pp * kWgPitch + p * 16) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < kWgTP / 16; ++ks) {
+            const bf16x8 Afr = load_tr_frag(s_dy, kWgPitch, ks * 16, ob * 32, lane);
+            // the 8 pixels of this lane half: two groups of 4 consecutive pixels
+            const int m0 = ks * 16 + h * 8;
+            const char* r0 = xb + (patch_index(g, m0) + lq) * kWgPitch;
+            const char* r1 = xb + (patch_index(g, m0 + 4) + lq) * kWgPitch;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * PW + (t % 3)) * kWgPitch;
+                const bf16x4 lo = lds_tr4(r0 + toff);
+                const bf16x4 hi = lds_tr4(r1 + toff);
+                const bf16x8 Bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[t] = mfma32(Afr, Bfr, acc[t]);
+            }
+        }
+    }
+    float* slab = part + static_cast<long>(blockIdx.x) * g.Cout * 9 * g.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = oc0 + ob * 32 + acc_row(r, lane);
+            slab[(static_cast<long>(oc) * 9 + t) * g.Cin + ic0 + ib * 32 + (lane & 31)] = acc[t][r];
+        }
+}
+
+// dw[i] = sum over slabs, four consecutive elements per thread
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ dw, long n4, int slabs) {
+    const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* p = reinterpret_cast<const float4*>(part) + i;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int s = 0; s < slabs; ++s) {
+        const float4 v = p[static_cast<long>(s) * n4];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    bf16x4 o;
+    o[0] = f2bf(a.x); o[1] = f2bf(a.y); o[2] = f2bf(a.z); o[3] = f2bf(a.w);
+    *reinterpret_cast<bf16x4*>(dw + i * 4) = o;
+}
+
+// ---------------------------------------------------------------------------
+inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Geometry of tiles of tp pixels; false when the shape is not supported.
+bool make_geo(int B, int H, int W, int Cin, int Cout, int tp, int max_patch, ConvGeo* g) {
+    if (!pow2(H) || !pow2(W) || W < 4 || W > 64 || H > 64 || B <= 0) return false;
+    if (Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0) return false;
+    if (tp % W != 0) return false;
+    const long M = static_cast<long>(B) * H * W;
+    if (M % tp != 0 || M * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;
+    const int rows = tp / W;
+    g->H = H; g->W = W; g->logH = ilog2(H); g->logW = ilog2(W);
+    g->RI = rows < H ? rows : H;
+    g->logRI = ilog2(g->RI);
+    g->NI = rows / g->RI;
+    g->np = g->NI * (g->RI + 2) * (W + 2);
+    g->Cin = Cin; g->Cout = Cout;
+    return g->np <= max_patch;
+}
+
+// forward tile choice: 128-pixel tiles while they make >= 256 workgroups
+int fwd_tile_pixels(int B, int H, int W, int Cout) {
+    const long M = static_cast<long>(B) * H * W;
+    return (M / 128) * (Cout / 64) >= 256 && M % 128 == 0 ? 128 : 64;
+}
+
+int g_wgrad_min_wgs = 192;
+
+inline int set_lds(const void* fn, int bytes) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? 0
+               : -20;
+}
+
+// pixel ranges of the weight gradient: as few slabs as keep g_wgrad_min_wgs
+// workgroups in flight, at least one iteration of 128 pixels each
+int wgrad_iterations(long M, int Cin, int Cout) {
+    const long tiles = static_cast<long>(Cin / 64) * (Cout / 64);
+    const long iters = M / kWgTP;
+    long nit = 1;
+    while (nit * 2 <= iters && (iters / (nit * 2)) * tiles >= g_wgrad_min_wgs && iters % (nit * 2) == 0) nit *= 2;
+    return static_cast<int>(nit);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when nf_conv3x3_fwd / nf_conv3x3_wgrad handle this shape.
+int nf_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
+    ConvGeo g;
+    if (!make_geo(B, H, W, Cin, Cout, fwd_tile_pixels(B, H, W, Cout), kMaxPatchFwd, &g)) return 0;
+    if (!make_geo(B, H, W, Cout, Cin, fwd_tile_pixels(B, H, W, Cin), kMaxPatchFwd, &g)) return 0;
+    return make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g) ? 1 : 0;
+}
+
+// y[B][H][W][Cout] = conv3x3(x[B][H][W][Cin], w[Cout][3][3][Cin]), bf16.
+int nf_conv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin,
+                   int Cout, hipStream_t s) {
+    const int tp = fwd_tile_pixels(B, H, W, Cout);
+    ConvGeo g;
+    if (!make_geo(B, H, W, Cin, Cout, tp, kMaxPatchFwd, &g)) return -1;
+    if (!al16(x) || !al16(w) || !al16(y)) return -2;
+    const long M = static_cast<long>(B) * H * W;
+    const dim3 grid(static_cast<unsigned>(M / tp), Cout / 64);
+    int lds = kBBytes + g.np * kPitch;
+    if (lds < kRedBytes) lds = kRedBytes;
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* wp = static_cast<const bf16*>(w);
+    bf16* yp = static_cast<bf16*>(y);
+    static const int lds_ok =
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2>), 80 * 1024) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4>), 80 * 1024);
+    if (lds_ok != 0 || lds > 80 * 1024) return -20;
+    if (tp == 128)
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2>), grid, dim3(256), lds, s, xp, wp, yp, g);
+    else
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4>), grid, dim3(256), lds, s, xp, wp, yp, g);
+    return static_cast<int>(hipGetLastError());
+}
+
+// wt[Cin][3][3][Cout] = w[Cout][3][3][Cin] with reversed taps.
+int nf_conv3x3_flip_weights(const void* w, void* wt, int Cin, int Cout, hipStream_t s) {
+    if (Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0) return -1;
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(9, Cout / 64, Cin / 64), dim3(256), 0, s,
+                       static_cast<const bf16*>(w), static_cast<bf16*>(wt), Cin, Cout);
+    return static_cast<int>(hipGetLastError());
+}
+
+// Tuning knob: the weight gradient splits the pixels into as few ranges as still
+// make this many workgroups (default 192).
+void nf_conv3x3_set_wgrad_min_workgroups(int n) { g_wgrad_min_wgs = n < 1 ? 1 : n; }
+
+// floats of workspace nf_conv3x3_wgrad needs
+long nf_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
+    const long M = static_cast<long>(B) * H * W;
+    if (M % kWgTP != 0 || Cin % 64 != 0 || Cout % 64 != 0) return -1;
+    const int nit = wgrad_iterations(M, Cin, Cout);
+    return (M / kWgTP / nit) * static_cast<long>(Cout) * 9 * Cin;
+}
+
+// dw[Cout][3][3][Cin] (bf16) = weight gradient of the convolution above.
+int nf_conv3x3_wgrad(const void* x, const void* dy, void* dw, float* workspace, int B, int H,
+                     int W, int Cin, int Cout, hipStream_t s) {
+    ConvGeo g;
+    if (!make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g)) return -1;
+    if (!al16(x) || !al16(dy) || !al16(dw) || !al16(workspace)) return -2;
+    const long M = static_cast<long>(B) * H * W;
+    const int nit = wgrad_iterations(M, Cin, Cout);
+    const int slabs = static_cast<int>(M / kWgTP / nit);
+    const dim3 grid(slabs, (Cout / 64) * (Cin / 64));
+    static const int lds_ok = set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), kWgLds);
+    if (lds_ok != 0) return -20;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), kWgLds, s,
+                       static_cast<const bf16*>(x), static_cast<const bf16*>(dy), workspace, g, nit);
+    const long n4 = static_cast<long>(Cout) * 9 * Cin / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)),
+                       dim3(256), 0, s, workspace, static_cast<bf16*>(dw), n4, slabs);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // extern "C"

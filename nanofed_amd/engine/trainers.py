@@ -96,6 +96,10 @@ class TorchGroupTrainer(GroupTrainer):
         )
         self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, torch.Tensor]] = {}
         self._channels_last = self.device.type == "cuda" and shards.kind == "image"
+        if self._channels_last:
+            # let the convolution library time its kernels per shape once (during
+            # the eager warm-up steps) instead of taking its untuned default
+            torch.backends.cudnn.benchmark = True
 
     # -- one optimisation step of client k --------------------------------
     def _step(self, k: int, rows: torch.Tensor) -> None:
