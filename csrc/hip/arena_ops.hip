@@ -208,6 +208,64 @@ sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, long n, float lr,
 }
 
 // ---------------------------------------------------------------------------
+// SGD over a flat fp32 parameter buffer whose gradients are separate tensors
+// (what autograd hands out when it is not made to accumulate into a flat buffer):
+// entry e updates p[offset[e] .. offset[e] + numel[e]) from grad[e], fp32 or bf16.
+// The table travels by value in the kernel arguments, so a captured graph keeps it.
+constexpr int kSgdMaxTensors = 96;
+struct SgdTable {
+    const void* grad[kSgdMaxTensors];
+    long offset[kSgdMaxTensors];
+    int numel[kSgdMaxTensors];
+    unsigned bf16_mask[kSgdMaxTensors / 32];
+};
+
+__global__ void __launch_bounds__(kThreads)
+sgd_multi_kernel(float* __restrict__ params, __hip_bfloat16* __restrict__ shadow_base, SgdTable t,
+                 float lr, float weight_decay) {
+    const int e = blockIdx.y;
+    const int n = t.numel[e];
+    float* p = params + t.offset[e];
+    __hip_bfloat16* shadow = shadow_base ? shadow_base + t.offset[e] : nullptr;
+    const bool g_bf16 = (t.bf16_mask[e >> 5] >> (e & 31)) & 1u;
+    const float* gf = static_cast<const float*>(t.grad[e]);
+    const __hip_bfloat16* gh = static_cast<const __hip_bfloat16*>(t.grad[e]);
+    const int n4 = n >> 2;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        float4 gv;
+        if (g_bf16) {
+            const uint2 raw = reinterpret_cast<const uint2*>(gh)[i];
+            gv.x = __uint_as_float(raw.x << 16);
+            gv.y = __uint_as_float(raw.x & 0xFFFF0000u);
+            gv.z = __uint_as_float(raw.y << 16);
+            gv.w = __uint_as_float(raw.y & 0xFFFF0000u);
+        } else {
+            gv = reinterpret_cast<const float4*>(gf)[i];
+        }
+        pv.x -= lr * fmaf(weight_decay, pv.x, gv.x);
+        pv.y -= lr * fmaf(weight_decay, pv.y, gv.y);
+        pv.z -= lr * fmaf(weight_decay, pv.z, gv.z);
+        pv.w -= lr * fmaf(weight_decay, pv.w, gv.w);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        if (shadow) {
+            __hip_bfloat16 h[4] = {__float2bfloat16(pv.x), __float2bfloat16(pv.y),
+                                   __float2bfloat16(pv.z), __float2bfloat16(pv.w)};
+            reinterpret_cast<uint2*>(shadow)[i] = *reinterpret_cast<uint2*>(h);
+        }
+    }
+    const int tail = (n4 << 2) + blockIdx.x * blockDim.x + threadIdx.x;
+    if (tail < n) {
+        float pv = p[tail];
+        const float g = g_bf16 ? __bfloat162float(gh[tail]) : gf[tail];
+        pv -= lr * fmaf(weight_decay, pv, g);
+        p[tail] = pv;
+        if (shadow) shadow[tail] = __float2bfloat16(pv);
+    }
+}
+
+// ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads)
 philox_fill_kernel(float* __restrict__ out, long n, unsigned long long seed,
                    unsigned long long offset, long first, int mode, float scale,
@@ -317,6 +375,37 @@ int nf_sgd_step(float* p, float* g, long n, float lr, float weight_decay,
                        n, lr, weight_decay, zero_grad,
                        static_cast<__hip_bfloat16*>(bf16_shadow));
     return NF_CHECK_LAUNCH();
+}
+
+// Multi-tensor SGD (see sgd_multi_kernel).  grads[e] must be 16-byte aligned,
+// offsets multiples of 4 elements; is_bf16[e] != 0 marks bf16 gradients.
+// shadow (may be null) is a bf16 buffer parallel to params.
+int nf_sgd_multi(float* params, void* shadow, const void* const* grads, const long* offsets,
+                 const long* numels, const int* is_bf16, int count, float lr,
+                 float weight_decay, hipStream_t stream) {
+    if (count < 0) return -1;
+    for (int first = 0; first < count; first += kSgdMaxTensors) {
+        const int m = count - first < kSgdMaxTensors ? count - first : kSgdMaxTensors;
+        SgdTable t = {};
+        long largest = 0;
+        for (int e = 0; e < m; ++e) {
+            const long n = numels[first + e];
+            if (n < 0 || n >= (1L << 31) || (offsets[first + e] & 3) != 0) return -1;
+            if ((reinterpret_cast<uintptr_t>(grads[first + e]) & 15) != 0) return -2;
+            t.grad[e] = grads[first + e];
+            t.offset[e] = offsets[first + e];
+            t.numel[e] = static_cast<int>(n);
+            if (is_bf16[first + e]) t.bf16_mask[e >> 5] |= 1u << (e & 31);
+            if (n > largest) largest = n;
+        }
+        long bx = (largest / 4 + kThreads - 1) / kThreads;
+        if (bx > 64) bx = 64;
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(sgd_multi_kernel, dim3(static_cast<unsigned>(bx), m), dim3(kThreads), 0,
+                           stream, params, static_cast<__hip_bfloat16*>(shadow), t, lr,
+                           weight_decay);
+    }
+    return static_cast<int>(hipGetLastError());
 }
 
 int nf_philox_fill(float* out, long n, unsigned long long seed,

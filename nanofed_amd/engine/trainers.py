@@ -96,10 +96,73 @@ class TorchGroupTrainer(GroupTrainer):
         )
         self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, torch.Tensor]] = {}
         self._channels_last = self.device.type == "cuda" and shards.kind == "image"
+        # bf16 training without per-step casts and gradient accumulation kernels:
+        # matrices and convolution weights are bf16 leaves (views of a bf16 copy of
+        # the arena that the optimizer refreshes), autograd hands out each gradient
+        # as its own tensor, and one multi-tensor kernel applies them to the fp32
+        # arena.  DP needs the flat gradient buffer and keeps the accumulate path.
+        self._direct = self._amp and cfg.dp is None
+        self._shadow: torch.Tensor | None = None
+        self._leaves: list[list[tuple[nn.Parameter, int]]] = []
+        if self._direct:
+            self._bind_shadow()
+        # BatchNorm layers on the fused kernels leave their step counter to
+        # train_round, which bumps it once per epoch instead of once per step
+        self._bn_layers: list[list[nn.Module]] = [[] for _ in self.modules]
+        if self._channels_last and self._amp:
+            from nanofed_amd.ops import bn_ops
+
+            for k, module in enumerate(self.modules):
+                for m in module.modules():
+                    if isinstance(m, nn.BatchNorm2d) and bn_ops.channels_supported(m.num_features):
+                        m.defer_batch_count = True
+                        self._bn_layers[k].append(m)
         if self._channels_last:
             # let the convolution library time its kernels per shape once (during
             # the eager warm-up steps) instead of taking its untuned default
             torch.backends.cudnn.benchmark = True
+
+    def _bind_shadow(self) -> None:
+        layout = self.pool.layout
+        self._shadow = torch.empty(
+            len(self.pool), layout.trainable_numel, dtype=torch.bfloat16, device=self.device
+        )
+        for k, module in enumerate(self.modules):
+            leaves = []
+            for name, p in module.named_parameters():
+                seg = layout[name]
+                p.grad = None
+                if p.dim() >= 2:
+                    p.data = layout.view_of(self._shadow[k], seg)
+                leaves.append((p, seg.offset))
+            self._leaves.append(leaves)
+        self._refresh_shadow()
+
+    def _refresh_shadow(self, k: int | None = None) -> None:
+        """bf16 copy of the (new) fp32 parameters: after a broadcast of the global
+        model or a restore of the arena."""
+        n = self.pool.layout.trainable_numel
+        if k is None:
+            self._shadow.copy_(self.pool.data[:, :n])
+        else:
+            self._shadow[k].copy_(self.pool[k].data[:n])
+
+    def _apply_gradients(self, k: int) -> None:
+        cfg = self.cfg
+        grads, offsets = [], []
+        for p, off in self._leaves[k]:
+            g = p.grad
+            if g is None:
+                continue
+            if g.stride() != p.stride():  # bring it into the arena's element order
+                g = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device).copy_(g)
+            grads.append(g)
+            offsets.append(off)
+            p.grad = None
+        ops.sgd_multi(
+            self.pool[k].trainable, grads, offsets, cfg.learning_rate, cfg.weight_decay,
+            bf16_shadow=self._shadow[k],
+        )
 
     # -- one optimisation step of client k --------------------------------
     def _step(self, k: int, rows: torch.Tensor) -> None:
@@ -137,6 +200,8 @@ class TorchGroupTrainer(GroupTrainer):
         arena.data.copy_(keep)
         if arena.grad is not None:
             arena.grad.zero_()
+        if self._direct:
+            self._refresh_shadow(k)
         self._acc[k].copy_(keep_acc)
         live = [b for b in self.modules[k].buffers() if not b.dtype.is_floating_point]
         for b, saved in zip(live, int_bufs):
@@ -157,10 +222,13 @@ class TorchGroupTrainer(GroupTrainer):
         loss.backward()
         if cfg.dp is not None:
             self._privatise(k, int(rows.numel()))
-        ops.sgd_step(
-            arena.trainable, arena.grad, cfg.learning_rate, cfg.weight_decay,
-            zero_grad=True,
-        )
+        if self._direct:
+            self._apply_gradients(k)
+        else:
+            ops.sgd_step(
+                arena.trainable, arena.grad, cfg.learning_rate, cfg.weight_decay,
+                zero_grad=True,
+            )
         acc = self._acc[k]
         acc[0] += loss.detach()
         acc[1] += count_correct(out.detach(), y)
@@ -183,6 +251,8 @@ class TorchGroupTrainer(GroupTrainer):
         cfg = self.cfg
         G = len(self.pool)
         self.metrics.zero_()
+        if self._direct:
+            self._refresh_shadow()
         for k in range(G):
             for epoch in range(cfg.local_epochs):
                 self._acc[k].zero_()
@@ -191,6 +261,8 @@ class TorchGroupTrainer(GroupTrainer):
                 for s in range(steps):
                     rows = perm[s * cfg.batch_size : (s + 1) * cfg.batch_size]
                     self._step(k, rows)
+                for m in self._bn_layers[k]:
+                    m.num_batches_tracked += steps
             batches = self._acc[k, 2].clamp(min=1.0)
             self.metrics[k, M_SAMPLES] = float(self.shards.sizes[k])
             self.metrics[k, M_LOSS] = self._acc[k, 0] / batches

@@ -16,6 +16,7 @@ from .arena_ops import (
     l2_norm,
     philox_fill,
     scale_accumulate,
+    sgd_multi,
     sgd_step,
     sqnorm_finite,
     weighted_sum,
@@ -52,6 +53,7 @@ __all__ = [
     "mask_add_",
     "philox_fill",
     "scale_accumulate",
+    "sgd_multi",
     "sgd_step",
     "sqnorm_finite",
     "weighted_sum",

@@ -230,6 +230,87 @@ def sgd_step(
     )
 
 
+def sgd_multi(
+    params: torch.Tensor,
+    grads: list[torch.Tensor],
+    offsets: list[int],
+    lr: float,
+    weight_decay: float = 0.0,
+    bf16_shadow: torch.Tensor | None = None,
+) -> None:
+    """In-place SGD over a flat fp32 parameter buffer whose gradients are separate
+    tensors (fp32 or bf16): ``grads[i]``, read in its storage order, updates
+    ``params[offsets[i] : offsets[i] + grads[i].numel()]``.  One launch per 96
+    tensors; the optional bf16 copy of the parameters is refreshed for the updated
+    ranges in the same pass."""
+    if len(grads) != len(offsets):
+        raise DeviceError("sgd_multi: one offset per gradient tensor")
+    dev = params.device
+    if bf16_shadow is not None and (
+        bf16_shadow.dtype != torch.bfloat16 or bf16_shadow.numel() < params.numel()
+    ):
+        raise DeviceError("sgd_multi: bf16 shadow must be bfloat16 and cover the parameters")
+    for g, off in zip(grads, offsets):
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            raise DeviceError(f"sgd_multi: gradient dtype {g.dtype} is not supported")
+        if off < 0 or off + g.numel() > params.numel():
+            raise DeviceError("sgd_multi: gradient range outside the parameter buffer")
+    if dev.type != "cuda":
+        for g, off in zip(grads, offsets):
+            seg = params[off : off + g.numel()]
+            flat = _storage_order(g).to(torch.float32)
+            seg.sub_(lr * (flat + weight_decay * seg))
+            if bf16_shadow is not None:
+                bf16_shadow[off : off + g.numel()].copy_(seg)
+        return
+    library.require_flat_f32(params, "sgd_multi params")
+    n = len(grads)
+    if n == 0:
+        return
+    dense = []
+    for g in grads:
+        if g.device != dev:
+            raise DeviceError("sgd_multi: gradients must live on the parameters' device")
+        if not _is_dense(g) or g.data_ptr() % 16:
+            g = _storage_order(g).clone()
+        dense.append(g)
+    ptrs = (c_void_p * n)(*[g.data_ptr() for g in dense])
+    offs = (c_long * n)(*offsets)
+    nums = (c_long * n)(*[g.numel() for g in dense])
+    kinds = (c_int * n)(*[1 if g.dtype == torch.bfloat16 else 0 for g in dense])
+    library.check(
+        library.hip_lib().nf_sgd_multi(
+            _ptr(params), _ptr(bf16_shadow) if bf16_shadow is not None else c_void_p(0),
+            ptrs, offs, nums, kinds, c_int(n), c_float(lr), c_float(weight_decay),
+            library.stream_ptr(dev),
+        ),
+        "nf_sgd_multi",
+    )
+
+
+def _is_dense(t: torch.Tensor) -> bool:
+    """True when the tensor's elements fill one gap-free block of memory."""
+    if t.is_contiguous():
+        return True
+    sizes_strides = sorted(
+        ((st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1), key=lambda p: p[0]
+    )
+    expect = 1
+    for st, sz in sizes_strides:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def _storage_order(t: torch.Tensor) -> torch.Tensor:
+    """The elements of a dense tensor as a 1-D tensor in memory order."""
+    if t.is_contiguous():
+        return t.reshape(-1)
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))
+    return t.permute(order).reshape(-1)
+
+
 # ---------------------------------------------------------------------------
 def _host_philox(
     flat: torch.Tensor, seed: int, offset: int, first: int, mode: int,

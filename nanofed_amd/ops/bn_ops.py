@@ -47,6 +47,10 @@ def _p(t: torch.Tensor | None) -> c_void_p:
     return c_void_p(t.data_ptr() if t is not None else 0)
 
 
+def channels_supported(channels: int) -> bool:
+    return bool(_fn("nf_bn_supported")(channels))
+
+
 def fused_path_applies(x: torch.Tensor, training: bool, residual: torch.Tensor | None) -> bool:
     if not (training and x.device.type == "cuda" and x.dtype == torch.bfloat16 and x.dim() == 4):
         return False
@@ -105,12 +109,17 @@ class _BatchNormAct(torch.autograd.Function):
 
 def batch_norm_act(bn: nn.BatchNorm2d, x: torch.Tensor, residual: torch.Tensor | None = None,
                    relu: bool = True) -> torch.Tensor:
-    """``relu(batch_norm(x) + residual)`` with ``bn``'s parameters and buffers."""
+    """``relu(batch_norm(x) + residual)`` with ``bn``'s parameters and buffers.
+
+    A trainer that counts optimisation steps itself sets ``bn.defer_batch_count``
+    and adds the count to ``num_batches_tracked`` once per round, which saves one
+    tiny kernel per layer and step."""
     if bn.affine and bn.track_running_stats and bn.momentum is not None and fused_path_applies(
         x, bn.training, residual
     ):
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
+        if not getattr(bn, "defer_batch_count", False):
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
         return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    residual, relu, float(bn.momentum), float(bn.eps))
     out = bn(x)

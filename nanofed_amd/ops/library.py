@@ -44,6 +44,7 @@ def _signatures() -> dict:
         "nf_sqnorm_finite": ([P, L, P, P, P], I),
         "nf_clip_noise": ([P, P, L, P, F, F, U, U, P], I),
         "nf_sgd_step": ([P, P, L, F, F, I, P, P], I),
+        "nf_sgd_multi": ([P, P, P, P, P, P, I, F, F, P], I),
         "nf_philox_fill": ([P, L, U, U, L, I, F, I, P], I),
         "nf_scale_accumulate": ([P, P, L, F, F, P], I),
     }

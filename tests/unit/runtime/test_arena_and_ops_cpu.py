@@ -193,3 +193,25 @@ def test_channels_last_storage_keeps_values_binding_and_export():
     plain = ParameterArena(ArenaLayout.from_module(net), "cpu")
     plain.load_state_dict(arena.views())
     assert torch.equal(plain.state_dict()["3.weight"], want["3.weight"])
+
+
+def test_sgd_multi_matches_per_tensor_sgd_on_cpu():
+    from nanofed_amd import ops
+
+    torch.manual_seed(3)
+    params = torch.randn(64 + 128 + 16)
+    ref = params.clone()
+    shadow = torch.zeros(params.numel(), dtype=torch.bfloat16)
+    g0 = torch.randn(4, 4, 2, 2).contiguous(memory_format=torch.channels_last)  # 64, strided
+    g1 = torch.randn(128).to(torch.bfloat16)
+    ops.sgd_multi(params, [g0, g1], [0, 64], lr=0.1, weight_decay=0.01, bf16_shadow=shadow)
+    # storage order of the channels-last gradient is [O, H, W, I]
+    flat0 = g0.permute(0, 2, 3, 1).reshape(-1)
+    exp0 = ref[:64] - 0.1 * (flat0 + 0.01 * ref[:64])
+    exp1 = ref[64:192] - 0.1 * (g1.float() + 0.01 * ref[64:192])
+    assert torch.allclose(params[:64], exp0)
+    assert torch.allclose(params[64:192], exp1)
+    assert torch.equal(params[192:], ref[192:])
+    assert torch.equal(shadow[:192], params[:192].to(torch.bfloat16))
+    with pytest.raises(Exception):
+        ops.sgd_multi(params, [g1], [150], lr=0.1)
