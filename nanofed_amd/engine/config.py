@@ -51,6 +51,9 @@ class EngineConfig:
     backend: str = "auto"  # auto | native | torch
     dtype: str = "bf16"  # compute dtype of the local trainers: bf16 | fp32
     graph_capture: bool = True
+    # torch trainer: train the clients of a GPU concurrently, one HIP stream each
+    # (their kernels are too small to fill the chip one client at a time)
+    client_streams: bool = True
     reduce_algo: str = "auto"  # auto | allreduce | rs_ag
     drop_last: bool = False
     # native MNIST kernels: conv2 workgroups per image (1 or 3); 0 = choose from
