@@ -24,6 +24,7 @@ trained one after the other and share the activation and gradient buffers.
 
 from __future__ import annotations
 
+
 import torch
 import torch.nn.functional as F
 
@@ -98,10 +99,23 @@ class GPT2NativeTrainer(GroupTrainer):
         G = len(pool)
         n = self.layout.numel
         self.shadow = torch.zeros(G, n, dtype=BF16, device=self.device)
-        self.grad = torch.zeros(n, dtype=BF16, device=self.device)
-        self._gv = _views(self.layout, self.grad)
+        # Lanes: independent sets of activation / gradient buffers, one HIP stream
+        # each; client k trains on lane k % lanes, so steps of different clients
+        # can overlap on the GPU.  Two lanes measured 1.3x faster rounds, but four
+        # lanes hung: the GEMM library picks stream-K kernels for some of these
+        # shapes, whose workgroups wait for each other through memory, and two such
+        # kernels sharing the chip can wait forever.  Until every GEMM on this path
+        # is a kernel without inter-workgroup waits, one lane is used.
+        lanes = 1
+        self.lanes = max(1, lanes)
+        self._grads = [torch.zeros(n, dtype=BF16, device=self.device) for _ in range(self.lanes)]
+        self._gvs = [_views(self.layout, g) for g in self._grads]
+        self._streams = (
+            [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+            if self.lanes > 1 else None
+        )
         self._eval_shadow = torch.zeros(n, dtype=BF16, device=self.device)
-        self._bufs: dict[tuple[int, int], _Buffers] = {}
+        self._bufs: dict[tuple[int, int, int], _Buffers] = {}
         self._eval_inputs = data.eval_inputs
         # the kernels index the embedding table with the raw ids: check them once
         for toks in (shards.inputs, data.eval_inputs):
@@ -113,8 +127,8 @@ class GPT2NativeTrainer(GroupTrainer):
         self._acc = torch.zeros(G, 3, dtype=torch.float32, device=self.device)
 
     # -- buffers ------------------------------------------------------------
-    def _buffers(self, batch: int, seq: int) -> _Buffers:
-        key = (batch, seq)
+    def _buffers(self, batch: int, seq: int, lane: int = 0) -> _Buffers:
+        key = (batch, seq, lane)
         if key not in self._bufs:
             self._bufs[key] = _Buffers(self.m, batch, seq, self.device)
         return self._bufs[key]
@@ -156,8 +170,9 @@ class GPT2NativeTrainer(GroupTrainer):
         nn_ops.cross_entropy_fwd_bwd(b.logits, tgt, V, 1.0 / b.R, b.loss_rows, b.correct_rows)
 
     # -- backward -----------------------------------------------------------
-    def _backward(self, w: dict[str, torch.Tensor], tokens: torch.Tensor, b: _Buffers) -> None:
-        m, L, g = self.m, self.m.n_layer, self._gv
+    def _backward(self, w: dict[str, torch.Tensor], tokens: torch.Tensor, b: _Buffers,
+                  g: dict[str, torch.Tensor]) -> None:
+        m, L = self.m, self.m.n_layer
         V = m.vocab_size
         dlog = b.logits[:, :V]
         torch.mm(dlog.t(), b.lnf, out=g["wte.weight"])  # LM head shares the embedding matrix
@@ -194,14 +209,14 @@ class GPT2NativeTrainer(GroupTrainer):
                          b.batch, b.seq)
 
     # -- one optimisation step of client k ------------------------------------
-    def _step(self, k: int, tokens: torch.Tensor) -> None:
+    def _step(self, k: int, tokens: torch.Tensor, lane: int = 0) -> None:
         cfg = self.cfg
-        b = self._buffers(tokens.shape[0], tokens.shape[1] - 1)
+        b = self._buffers(tokens.shape[0], tokens.shape[1] - 1, lane)
         w = _views(self.layout, self.shadow[k])
         self._forward(w, tokens, b)
-        self._backward(w, tokens, b)
-        nn_ops.sgd_step_bf16g(self.pool[k].data, self.grad, self.shadow[k], cfg.learning_rate,
-                              cfg.weight_decay)
+        self._backward(w, tokens, b, self._gvs[lane])
+        nn_ops.sgd_step_bf16g(self.pool[k].data, self._grads[lane], self.shadow[k],
+                              cfg.learning_rate, cfg.weight_decay)
         acc = self._acc[k]
         acc[0] += b.loss_rows.mean()
         acc[1] += b.correct_rows.mean()
@@ -214,20 +229,49 @@ class GPT2NativeTrainer(GroupTrainer):
         self.shadow[k].copy_(self.pool[k].data)
         w = _views(self.layout, self.shadow[k])
         self._forward(w, tokens, b)
-        self._backward(w, tokens, b)
-        return float(b.loss_rows.mean()), self._gv
+        self._backward(w, tokens, b, self._gvs[0])
+        return float(b.loss_rows.mean()), self._gvs[0]
 
     def train_round(self, round_idx: int) -> torch.Tensor:
         cfg = self.cfg
+        G = len(self.pool)
         self.metrics.zero_()
-        for k in range(len(self.pool)):
-            self.shadow[k].copy_(self.pool[k].data)  # the round starts from the broadcast model
+        self.shadow.copy_(self.pool.data)  # the round starts from the broadcast model
+        steps = [self.shards.steps_per_epoch(k) for k in range(G)]
+        perms = [
+            [self.shards.epoch_permutation(k, round_idx, e) for e in range(cfg.local_epochs)]
+            for k in range(G)
+        ]
+        main = torch.cuda.current_stream() if self._streams else None
+        if self._streams:
+            for st in self._streams:
+                st.wait_stream(main)
+        # lane-major groups of clients, step-major inside a group: the lanes'
+        # streams always have a step of another client to overlap with
+        for first in range(0, G, self.lanes):
+            group = list(range(first, min(first + self.lanes, G)))
             for epoch in range(cfg.local_epochs):
-                self._acc[k].zero_()
-                perm = self.shards.epoch_permutation(k, round_idx, epoch)
-                for s in range(self.shards.steps_per_epoch(k)):
-                    rows = perm[s * cfg.batch_size : (s + 1) * cfg.batch_size]
-                    self._step(k, self.shards.inputs[rows])
+                for s in range(max(steps[k] for k in group)):
+                    for k in group:
+                        if s >= steps[k]:
+                            continue
+                        lane = k % self.lanes
+                        lo = s * cfg.batch_size
+                        rows = perms[k][epoch][lo : lo + cfg.batch_size]
+                        if self._streams:
+                            with torch.cuda.stream(self._streams[lane]):
+                                if s == 0:
+                                    self._acc[k].zero_()
+                                self._step(k, self.shards.inputs[rows], lane)
+                        else:
+                            if s == 0:
+                                self._acc[k].zero_()
+                            self._step(k, self.shards.inputs[rows], lane)
+        if self._streams:
+            for st in self._streams:
+                main.wait_stream(st)
+        del perms
+        for k in range(G):
             batches = self._acc[k, 2].clamp(min=1.0)
             self.metrics[k, M_SAMPLES] = float(self.shards.sizes[k])
             self.metrics[k, M_LOSS] = self._acc[k, 0] / batches

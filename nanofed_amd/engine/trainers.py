@@ -21,6 +21,7 @@ a fully hand-written path on top of this interface
 
 from __future__ import annotations
 
+import os
 from typing import Callable
 
 import torch
@@ -117,10 +118,18 @@ class TorchGroupTrainer(GroupTrainer):
                     if isinstance(m, nn.BatchNorm2d) and bn_ops.channels_supported(m.num_features):
                         m.defer_batch_count = True
                         self._bn_layers[k].append(m)
-        # one stream per client (default priority)
+        # Client streams (default priority) for the convolutional models.  Token
+        # models stay on one stream: their large GEMMs may run as stream-K kernels,
+        # whose workgroups wait for each other through memory - two of those
+        # sharing the chip can wait forever (seen with the GPT-2 trainer).
         self._streams: list[torch.cuda.Stream] | None = None
-        if cfg.client_streams and self.device.type == "cuda" and len(pool) > 1:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(len(pool))]
+        if (cfg.client_streams and self.device.type == "cuda" and len(pool) > 1
+                and shards.kind == "image"):
+            # more streams than hardware queues (4 per process by default) bring
+            # nothing; NANOFED_CLIENT_STREAMS overrides the count for experiments
+            ns = min(len(pool), int(os.environ.get("NANOFED_CLIENT_STREAMS", "4")))
+            base = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
+            self._streams = [base[k % ns] for k in range(len(pool))]
         if self._channels_last:
             # let the convolution library time its kernels per shape once (during
             # the eager warm-up steps) instead of taking its untuned default
@@ -294,8 +303,9 @@ class TorchGroupTrainer(GroupTrainer):
             [self.shards.epoch_permutation(k, round_idx, e) for e in range(cfg.local_epochs)]
             for k in range(G)
         ]
-        for st in self._streams:
+        for st in set(self._streams):
             st.wait_stream(main)
+
         for epoch in range(cfg.local_epochs):
             for k in range(G):
                 with torch.cuda.stream(self._streams[k]):
@@ -304,13 +314,13 @@ class TorchGroupTrainer(GroupTrainer):
                 for k in range(G):
                     if s < steps[k]:
                         with torch.cuda.stream(self._streams[k]):
-                            rows = perms[k][epoch][s * cfg.batch_size : (s + 1) * cfg.batch_size]
-                            self._step(k, rows)
+                            lo = s * cfg.batch_size
+                            self._step(k, perms[k][epoch][lo : lo + cfg.batch_size])
             for k in range(G):
                 with torch.cuda.stream(self._streams[k]):
                     for m in self._bn_layers[k]:
                         m.num_batches_tracked += steps[k]
-        for st in self._streams:
+        for st in set(self._streams):
             main.wait_stream(st)
         del perms  # released only after the main stream has joined the client streams
 
