@@ -45,3 +45,44 @@ def test_resnet_bf16_graph_tracks_eager_and_learns():
     _, losses, _ = _run(True, rounds=4, **kw)
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0]
+
+
+def test_client_streams_train_the_same_models():
+    """Four clients on concurrent streams (two of them share a stream when
+    NANOFED_CLIENT_STREAMS is lowered) against the same clients trained one after
+    another: fp32 runs of a model without dropout (whose masks depend on the launch
+    order) must agree closely."""
+    kw = dict(model="mnist_mlp", model_kwargs={"hidden": 64}, backend="torch", num_clients=4,
+              local_epochs=2, batch_size=32, samples_per_client=160, eval_samples=64,
+              dtype="fp32", learning_rate=0.05, seed=5)
+    outs = []
+    for streams in (False, True):
+        torch.cuda.set_device(0)
+        eng = FederatedEngine(EngineConfig(client_streams=streams, **kw),
+                              comm=Communicator(device=torch.device("cuda", 0)))
+        reps = eng.run(2)
+        assert (eng.trainer._streams is not None) == streams
+        outs.append((eng.global_arena.data.float().cpu(), [r.agg_metrics["loss"] for r in reps]))
+    (a, la), (b, lb) = outs
+    torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-4)
+    assert lb == pytest.approx(la, rel=1e-3)
+
+
+def test_resnet_streams_count_batchnorm_steps():
+    kw = dict(model="resnet18", dataset="synthetic_cifar10", backend="torch", num_clients=4,
+              local_epochs=1, batch_size=32, samples_per_client=96, eval_samples=64,
+              learning_rate=0.05, seed=2)
+    torch.cuda.set_device(0)
+    eng = FederatedEngine(EngineConfig(**kw), comm=Communicator(device=torch.device("cuda", 0)))
+    reps = eng.run(2)
+    assert all(r.status == "COMPLETED" for r in reps)
+    tr = eng.trainer
+    assert tr._streams is not None and tr._direct
+    # 3 steps per epoch, 2 rounds; the counter restarts from the averaged global
+    # value every round, so every client's module reads 3 after its last epoch...
+    counts = {int(m.num_batches_tracked) for layers in tr._bn_layers for m in layers}
+    assert len(counts) == 1 and counts.pop() >= 3
+    # ... and every weight leaf is a bf16 view of the shadow arena without a gradient
+    for p, _ in tr._leaves[0]:
+        assert p.grad is None
+        assert p.dtype == (torch.bfloat16 if p.dim() >= 2 else torch.float32)
