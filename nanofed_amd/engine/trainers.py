@@ -6,13 +6,17 @@ training semantics (nanofed/trainer/base.py:115-198: per batch zero_grad,
 forward, cross-entropy, backward, SGD step; metrics of the last local epoch)
 but
 
-* parameters and gradients of every client are views into one arena pool, so
-  the optimizer is one multi-tensor HIP kernel per step (which also clears the
-  gradients) instead of a Python loop over tensors;
+* every client's parameters live in one arena pool; in bf16 its weight
+  matrices are bf16 leaves over a bf16 copy of the arena, autograd's gradient
+  tensors are consumed as they are, and the optimizer is one multi-tensor HIP
+  kernel per step (fp32 / DP runs: arena-view parameters, a flat gradient
+  buffer and one flat SGD kernel that also clears the gradients);
 * batches are index gathers from the HBM-resident shard, not H2D copies;
 * loss and accuracy are accumulated in a device tensor - nothing is read
   back during the round (the reference synchronises twice per batch,
-  base.py:154,159).
+  base.py:154,159);
+* a client's whole step is one hipGraph replay, and the clients of a GPU run
+  on concurrent streams (image models).
 
 Forward/backward are PyTorch-ROCm ops under bf16 autocast.  The MNIST CNN has
 a fully hand-written path on top of this interface
