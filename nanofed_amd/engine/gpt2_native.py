@@ -24,6 +24,8 @@ trained one after the other and share the activation and gradient buffers.
 
 from __future__ import annotations
 
+import os
+
 
 import torch
 import torch.nn.functional as F
@@ -39,6 +41,10 @@ from .data import DeviceShards, FederatedData
 from .trainers import M_ACC, M_LOSS, M_SAMPLES, M_VALID, METRIC_COLUMNS, GroupTrainer
 
 BF16 = torch.bfloat16
+
+
+# concurrent client steps of the profiled shape (see GPT2NativeTrainer.__init__)
+LANES = int(os.environ.get("NANOFED_GPT2_LANES", "1"))
 
 
 def _views(layout: ArenaLayout, flat: torch.Tensor) -> dict[str, torch.Tensor]:
@@ -101,13 +107,25 @@ class GPT2NativeTrainer(GroupTrainer):
         self.shadow = torch.zeros(G, n, dtype=BF16, device=self.device)
         # Lanes: independent sets of activation / gradient buffers, one HIP stream
         # each; client k trains on lane k % lanes, so steps of different clients
-        # can overlap on the GPU.  Two lanes measured 1.3x faster rounds, but four
-        # lanes hung: the GEMM library picks stream-K kernels for some of these
-        # shapes, whose workgroups wait for each other through memory, and two such
-        # kernels sharing the chip can wait forever.  Until every GEMM on this path
-        # is a kernel without inter-workgroup waits, one lane is used.
+        # overlap on the GPU (many kernels of a 4096-row step leave compute units
+        # idle): two lanes measured 3.45 -> 4.73 rounds/s.  FOUR lanes hung the
+        # process twice (no GPU fault), the second time with the one stream-K GEMM
+        # of the step - the LM-head forward, whose workgroups wait for each other
+        # through memory - serialised across lanes, so the cause is not understood.
+        # Lanes are therefore opt-in (NANOFED_GPT2_LANES=2), never more than two,
+        # and only for the step shape whose kernel trace was inspected (GPT-2
+        # small, 4096 rows per step, full batches); the default is one lane.
+        if LANES > 2:
+            raise DeviceError("NANOFED_GPT2_LANES: more than two lanes hung the GPU queue; use 1 or 2")
         lanes = 1
+        rows = cfg.batch_size * cfg.seq_len
+        profiled = (model_cfg.n_embd, model_cfg.vocab_size, rows) == (768, 50257, 4096)
+        full_batches = all(sz % cfg.batch_size == 0 for sz in shards.sizes)
+        if (cfg.client_streams and self.device.type == "cuda" and G > 1 and profiled
+                and full_batches):
+            lanes = min(G, max(LANES, 1))
         self.lanes = max(1, lanes)
+        self._lm_head_done = torch.cuda.Event() if self.lanes > 1 else None
         self._grads = [torch.zeros(n, dtype=BF16, device=self.device) for _ in range(self.lanes)]
         self._gvs = [_views(self.layout, g) for g in self._grads]
         self._streams = (
@@ -166,7 +184,13 @@ class GPT2NativeTrainer(GroupTrainer):
         stf = b.stats[2 * L]
         nn_ops.ln_fwd(b.x_mid[L - 1], w["ln_f.weight"], w["ln_f.bias"], b.lnf, stf[0], stf[1],
                       delta=delta, x_out=b.x[L])
-        torch.mm(b.lnf, w["wte.weight"].t(), out=b.logits[:, :V])
+        if self._lm_head_done is None:
+            torch.mm(b.lnf, w["wte.weight"].t(), out=b.logits[:, :V])
+        else:  # never two of these at once, whatever the lane
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._lm_head_done)
+            torch.mm(b.lnf, w["wte.weight"].t(), out=b.logits[:, :V])
+            self._lm_head_done.record(cur)
         nn_ops.cross_entropy_fwd_bwd(b.logits, tgt, V, 1.0 / b.R, b.loss_rows, b.correct_rows)
 
     # -- backward -----------------------------------------------------------
