@@ -35,13 +35,20 @@ using namespace nfd;
 
 namespace {
 
-constexpr int kChunk = 32;              // input channels per staging step (forward)
-constexpr int kPitch = kChunk * 2 + 16; // 80 bytes per staged pixel / weight row
-constexpr int kBRows = 64 * 9;
-constexpr int kBBytes = kBRows * kPitch;  // 46080
-constexpr int kMaxAPieces = 5;            // ceil(max patch pixels * 4 / 256)
-constexpr int kMaxPatchFwd = kMaxAPieces * 64;
+constexpr int kBRows = 64 * 9;            // weight rows of an output-channel tile
+constexpr int kMaxAPieces = 5;            // 16-byte patch pieces per thread and chunk
 constexpr int kRedBytes = 4 * 4 * 16 * 64 * 4;  // accumulators of four waves
+
+// forward staging for chunks of CH input channels
+template <int CH>
+struct FwdStage {
+    static constexpr int kPitch = CH * 2 + 16;        // bytes per staged pixel / weight row
+    static constexpr int kPieces = CH / 8;            // 16-byte pieces per row
+    static constexpr int kBBytes = kBRows * kPitch;
+    static constexpr int kBPerThread = kBRows * kPieces / 256;
+    static constexpr int kMaxPatch = kMaxAPieces * 256 / kPieces;  // 320 (CH 32), 160 (CH 64)
+    static constexpr int kSteps = 9 * CH / 16;        // MFMA k-steps per chunk
+};
 
 struct ConvGeo {
     int H, W, logH, logW;  // image size
@@ -74,15 +81,18 @@ __device__ __forceinline__ int patch_index(const ConvGeo& g, int m) {
     return (band * (g.RI + 2) + r) * (g.W + 2) + xx;
 }
 
-template <int PXW, int KSW>
+template <int PXW, int KSW, int CH>
 __global__ void __launch_bounds__(256)
 conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
                    ConvGeo g) {
     static_assert(PXW * KSW == 4, "four waves");
+    using St = FwdStage<CH>;
     constexpr int TP = 64 * PXW;
+    constexpr int kPitch = St::kPitch, kPieces = St::kPieces;
+    constexpr int kLog = CH == 32 ? 2 : 3;  // log2(kPieces)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_b = smem;            // [64 oc * 9 taps][32 ic], pitch 80
-    char* s_a = smem + kBBytes;  // [patch pixel][32 ic], pitch 80
+    char* s_b = smem;                 // [64 oc * 9 taps][CH ic]
+    char* s_a = smem + St::kBBytes;   // [patch pixel][CH ic]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pw = wave % PXW, kw = wave / PXW;
     const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
@@ -93,7 +103,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     int a_src[kMaxAPieces], a_dst[kMaxAPieces];
 #pragma unroll
     for (int i = 0; i < kMaxAPieces; ++i) {
-        const int q = tid + i * 256, pp = q >> 2, p = q & 3;
+        const int q = tid + i * 256, pp = q >> kLog, p = q & (kPieces - 1);
         if (pp < g.np) {
             const int src = patch_source(g, row0, pp);
             a_src[i] = src < 0 ? -1 : src + p * 8;
@@ -113,30 +123,63 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
         b_row[nb] = (nb * 32 + (lane & 31)) * 9 * kPitch + (lane >> 5) * 16;
 
     f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
-    const int s_lo = (18 * kw) / KSW, s_hi = (18 * (kw + 1)) / KSW;
-    const int nchunks = g.Cin / kChunk;
+    const int s_lo = (St::kSteps * kw) / KSW, s_hi = (St::kSteps * (kw + 1)) / KSW;
+    const int nchunks = g.Cin / CH;
     const bf16* wsrc = w + static_cast<long>(oc0) * 9 * g.Cin;
+
+    // chunk c + 1 travels memory -> registers while chunk c is being multiplied
+    // (named registers: an indexed array that lives across loop iterations ends up
+    // in scratch memory)
+#define NF_B_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) \
+    X(14) X(15) X(16) X(17)
+#define NF_A_LIST(X) X(0) X(1) X(2) X(3) X(4)
+#define NF_DECL_B(i) uint4 pb##i = make_uint4(0u, 0u, 0u, 0u);
+#define NF_DECL_A(i) uint4 pa##i = make_uint4(0u, 0u, 0u, 0u);
+    NF_B_LIST(NF_DECL_B)
+    NF_A_LIST(NF_DECL_A)
+    static_assert(St::kBPerThread <= 18 && kMaxAPieces == 5, "named prefetch registers");
+    int chunk_off = 0;  // c * CH of the chunk being fetched
+#define NF_LOAD_B(i)                                                                      \
+    if constexpr (i < St::kBPerThread) {                                                  \
+        const int q = tid + i * 256, row = q >> kLog, p = q & (kPieces - 1);              \
+        pb##i = *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * g.Cin +   \
+                                                chunk_off + p * 8);                       \
+    }
+#define NF_LOAD_A(i)                                                                      \
+    {                                                                                     \
+        pa##i = make_uint4(0u, 0u, 0u, 0u);                                               \
+        if (a_src[i] >= 0) pa##i = *reinterpret_cast<const uint4*>(x + a_src[i] + chunk_off); \
+    }
+#define NF_STORE_B(i)                                                                     \
+    if constexpr (i < St::kBPerThread) {                                                  \
+        const int q = tid + i * 256, row = q >> kLog, p = q & (kPieces - 1);              \
+        *reinterpret_cast<uint4*>(s_b + row * kPitch + p * 16) = pb##i;                   \
+    }
+#define NF_STORE_A(i) \
+    if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(s_a + a_dst[i]) = pa##i;
+    NF_B_LIST(NF_LOAD_B)
+    NF_A_LIST(NF_LOAD_A)
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int q = tid + i * 256, row = q >> 2, p = q & 3;
-            const uint4 v = *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * g.Cin +
-                                                            c * kChunk + p * 8);
-            *reinterpret_cast<uint4*>(s_b + row * kPitch + p * 16) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < kMaxAPieces; ++i) {
-            if (a_dst[i] >= 0) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (a_src[i] >= 0) v = *reinterpret_cast<const uint4*>(x + a_src[i] + c * kChunk);
-                *reinterpret_cast<uint4*>(s_a + a_dst[i]) = v;
-            }
+        NF_B_LIST(NF_STORE_B)
+        NF_A_LIST(NF_STORE_A)
+        if (c + 1 < nchunks) {
+            chunk_off = (c + 1) * CH;
+            NF_B_LIST(NF_LOAD_B)
+            NF_A_LIST(NF_LOAD_A)
         }
         __syncthreads();
-#pragma unroll 2
+#undef NF_B_LIST
+#undef NF_A_LIST
+#undef NF_DECL_B
+#undef NF_DECL_A
+#undef NF_LOAD_B
+#undef NF_LOAD_A
+#undef NF_STORE_B
+#undef NF_STORE_A
+#pragma unroll 3
         for (int s = s_lo; s < s_hi; ++s) {
-            const int tap = s >> 1, sub = s & 1;
+            const int tap = s / (CH / 16), sub = s - tap * (CH / 16);
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int aoff = (ky * PW + kx) * kPitch + sub * 32;
             const int boff = tap * kPitch + sub * 32;
@@ -348,10 +391,17 @@ bool make_geo(int B, int H, int W, int Cin, int Cout, int tp, int max_patch, Con
     return g->np <= max_patch;
 }
 
-// forward tile choice: 128-pixel tiles while they make >= 256 workgroups
+// forward tile choice: 128-pixel tiles (2 x 2 waves, chunks of 32 channels) while
+// they make >= 256 workgroups, else 64-pixel tiles (1 x 4 waves, chunks of 64)
 int fwd_tile_pixels(int B, int H, int W, int Cout) {
     const long M = static_cast<long>(B) * H * W;
     return (M / 128) * (Cout / 64) >= 256 && M % 128 == 0 ? 128 : 64;
+}
+
+bool fwd_geo(int B, int H, int W, int Cin, int Cout, ConvGeo* g) {
+    const int tp = fwd_tile_pixels(B, H, W, Cout);
+    const int max_patch = tp == 128 ? FwdStage<32>::kMaxPatch : FwdStage<64>::kMaxPatch;
+    return make_geo(B, H, W, Cin, Cout, tp, max_patch, g);
 }
 
 int g_wgrad_min_wgs = 192;
@@ -379,8 +429,8 @@ extern "C" {
 // 1 when nf_conv3x3_fwd / nf_conv3x3_wgrad handle this shape.
 int nf_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
     ConvGeo g;
-    if (!make_geo(B, H, W, Cin, Cout, fwd_tile_pixels(B, H, W, Cout), kMaxPatchFwd, &g)) return 0;
-    if (!make_geo(B, H, W, Cout, Cin, fwd_tile_pixels(B, H, W, Cin), kMaxPatchFwd, &g)) return 0;
+    if (!fwd_geo(B, H, W, Cin, Cout, &g)) return 0;
+    if (!fwd_geo(B, H, W, Cout, Cin, &g)) return 0;
     return make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g) ? 1 : 0;
 }
 
@@ -389,23 +439,31 @@ int nf_conv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, i
                    int Cout, hipStream_t s) {
     const int tp = fwd_tile_pixels(B, H, W, Cout);
     ConvGeo g;
-    if (!make_geo(B, H, W, Cin, Cout, tp, kMaxPatchFwd, &g)) return -1;
+    if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
     if (!al16(x) || !al16(w) || !al16(y)) return -2;
     const long M = static_cast<long>(B) * H * W;
     const dim3 grid(static_cast<unsigned>(M / tp), Cout / 64);
-    int lds = kBBytes + g.np * kPitch;
-    if (lds < kRedBytes) lds = kRedBytes;
     const bf16* xp = static_cast<const bf16*>(x);
     const bf16* wp = static_cast<const bf16*>(w);
     bf16* yp = static_cast<bf16*>(y);
+    constexpr int kLdsCap = 112 * 1024;
     static const int lds_ok =
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2>), 80 * 1024) |
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4>), 80 * 1024);
-    if (lds_ok != 0 || lds > 80 * 1024) return -20;
-    if (tp == 128)
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2>), grid, dim3(256), lds, s, xp, wp, yp, g);
-    else
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4>), grid, dim3(256), lds, s, xp, wp, yp, g);
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32>), kLdsCap) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64>), kLdsCap);
+    if (lds_ok != 0) return -20;
+    if (tp == 128) {
+        using St = FwdStage<32>;
+        int lds = St::kBBytes + g.np * St::kPitch;
+        if (lds < kRedBytes) lds = kRedBytes;
+        if (lds > kLdsCap) return -20;
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32>), grid, dim3(256), lds, s, xp, wp, yp, g);
+    } else {
+        using St = FwdStage<64>;
+        int lds = St::kBBytes + g.np * St::kPitch;
+        if (lds < kRedBytes) lds = kRedBytes;
+        if (lds > kLdsCap) return -20;
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64>), grid, dim3(256), lds, s, xp, wp, yp, g);
+    }
     return static_cast<int>(hipGetLastError());
 }
 

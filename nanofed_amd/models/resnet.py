@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from nanofed_amd.ops.bn_ops import batch_norm_act
+from nanofed_amd.ops.conv_ops import conv2d
 
 
 class BasicBlock(nn.Module):
@@ -32,13 +33,14 @@ class BasicBlock(nn.Module):
             )
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # BatchNorm, the residual add and the ReLU are one fused op on the GPU
-        out = batch_norm_act(self.bn1, self.conv1(x))
+        # BatchNorm, the residual add and the ReLU are one fused op on the GPU; the
+        # stride-1 3x3 convolutions run on the hand-written MFMA kernels there
+        out = batch_norm_act(self.bn1, conv2d(self.conv1, x))
         if len(self.shortcut) == 0:
             short = x
         else:
             short = batch_norm_act(self.shortcut[1], self.shortcut[0](x), relu=False)
-        return batch_norm_act(self.bn2, self.conv2(out), residual=short)
+        return batch_norm_act(self.bn2, conv2d(self.conv2, out), residual=short)
 
 
 class ResNet18(nn.Module):

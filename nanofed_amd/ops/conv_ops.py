@@ -13,6 +13,7 @@ serves the ResNet-18 configuration of the benchmark suite.
 
 from __future__ import annotations
 
+import os
 from ctypes import c_int, c_long, c_void_p
 
 import torch
@@ -113,6 +114,17 @@ def conv3x3_weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+# The weight gradient of the library (autotuned) is still faster than
+# conv3x3_weight_grad for the ResNet shapes, so the autograd op uses it by default.
+NATIVE_WEIGHT_GRAD = os.environ.get("NANOFED_CONV_NATIVE_WGRAD", "0") == "1"
+
+
+def library_weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    return torch.ops.aten.convolution_backward(
+        dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]
+    )[1]
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -126,7 +138,9 @@ class _Conv3x3(torch.autograd.Function):
         if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=CL):
             dy = dy.to(torch.bfloat16).contiguous(memory_format=CL)
         dx = conv3x3_input_grad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = conv3x3_weight_grad(x, dy) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_weight_grad(x, dy) if NATIVE_WEIGHT_GRAD else library_weight_grad(x, dy, w)
         return dx, dw
 
 

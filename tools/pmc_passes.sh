@@ -2,7 +2,8 @@
 # Hardware-counter passes over a short program, one rocprofv3 run per pass (the
 # counter blocks cannot be shared between passes).  Usage:
 #   tools/pmc_passes.sh <out_dir> <python script> [args...]
-# Writes <out_dir>/<pass>/... and a per-kernel summary <out_dir>/<pass>.csv.
+# Writes <out_dir>/<pass>/... and a per-kernel summary <out_dir>/<pass>.csv
+# (PMC_SUMMARY_FLAGS=--by-grid: one row per kernel and grid size).
 set -uo pipefail
 out="$1"; shift
 root="$(cd "$(dirname "$0")/.." && pwd)"
@@ -20,7 +21,7 @@ for name in mfma lds fetch write; do
       -d "$out/$name" -o "$name" -- python3 "$@" > "$out/$name.log" 2>&1
   rc=$?
   if [ $rc -ne 0 ]; then echo "[pmc] pass $name failed ($rc)"; tail -5 "$out/$name.log"; exit $rc; fi
-  python3 "$root/tools/summarize_pmc.py" "$out/$name" > "$out/$name.csv"
+  python3 "$root/tools/summarize_pmc.py" "$out/$name" ${PMC_SUMMARY_FLAGS:-} > "$out/$name.csv"
   find "$out/$name" -name "*.csv" -size +2M -delete
 done
 echo "[pmc] done"
