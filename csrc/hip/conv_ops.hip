@@ -10,21 +10,23 @@
 // (raster order over image, row, column) by 64 output channels.  The pixels of
 // a tile form NI bands of RI image rows; the bands are staged in LDS with a halo
 // of one pixel, so the nine taps are nine shifted reads of one patch.  The
-// reduction runs over chunks of 32 input channels: per chunk the patch and the
-// [64 oc][9 taps][32 ic] weight slice are staged (pitch 80 bytes: 16-byte
-// row-major fragment reads without bank conflicts), which makes 18 MFMA k-steps.
-// Waves are arranged PXW x KSW: PXW pixel groups of 64 pixels, KSW waves sharing
-// the k-steps of one pixel group; the partial accumulators of a pixel group are
-// summed through LDS at the end.  Deep layers (few pixels, many channels) use
-// 1 x 4 so that a layer still makes >= 128 workgroups; wide layers 2 x 2.
+// reduction runs over chunks of CH (32 or 64) input channels: per chunk the patch
+// and the [64 oc][9 taps][CH ic] weight slice are staged (pitch 2 CH + 16 bytes:
+// 16-byte row-major fragment reads), which makes 9 CH / 16 MFMA k-steps; the next
+// chunk is fetched into registers meanwhile.  Waves are arranged PXW x KSW: PXW
+// pixel groups of 64 pixels, KSW waves sharing the k-steps of one pixel group; the
+// partial accumulators of a pixel group are summed through LDS at the end.  Deep
+// layers (few pixels, many channels) use 1 x 4 with chunks of 64 so that a layer
+// still makes >= 128 workgroups; wide layers 2 x 2 with chunks of 32.
 //
 // Weight gradient.  dW[oc][tap][ic] = sum over pixels dY[px][oc] * X[px + tap][ic]:
 // both operands have the reduction index (pixels) as the slow dimension in
 // memory, so both fragments come from transposing LDS reads.  A workgroup owns a
 // 64 oc x 64 ic tile for a range of pixels; each wave accumulates a 32 x 32
 // sub-tile for all nine taps (144 accumulator registers; one dY fragment feeds
-// nine MFMAs).  Pixel ranges write fp32 partial slabs that a second kernel sums
-// in a fixed order (no atomics: results do not depend on scheduling).
+// nine MFMAs).  Pixel ranges write partial slabs (bf16: the kernel is bound by
+// this traffic, and the sum itself is bf16) that a second kernel sums in fp32 in a
+// fixed order (no atomics: results do not depend on scheduling).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -258,9 +260,9 @@ constexpr int kWgDyBytes = kWgTP * kWgPitch;  // 20480
 constexpr int kWgMaxPatch = 288;
 constexpr int kWgLds = kWgDyBytes + kWgMaxPatch * kWgPitch;  // 66560
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256)
 conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
-                     float* __restrict__ part, ConvGeo g, int nit) {
+                     bf16* __restrict__ part, ConvGeo g, int nit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_dy = smem;               // [128 px][64 oc], pitch 160
     char* s_x = smem + kWgDyBytes;   // [patch pixel][64 ic], pitch 160
@@ -294,33 +296,65 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x16{0};
 
+    // tile t + 1 travels memory -> registers while tile t is being multiplied
+    // (named registers: an indexed array across loop iterations lands in scratch)
+#define NF_DY_LIST(X) X(0) X(1) X(2) X(3)
+#define NF_X_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define NF_DECL_DY(i) uint4 pdy##i = make_uint4(0u, 0u, 0u, 0u);
+#define NF_DECL_X(i) uint4 px##i = make_uint4(0u, 0u, 0u, 0u);
+    NF_DY_LIST(NF_DECL_DY)
+    NF_X_LIST(NF_DECL_X)
+    int ftile = blockIdx.x * nit;  // tile being fetched
+#define NF_LOAD_DY(i)                                                                     \
+    {                                                                                     \
+        const int q = tid + i * 256, pix = q >> 3, p = q & 7;                             \
+        pdy##i = *reinterpret_cast<const uint4*>(                                         \
+            dy + (static_cast<long>(ftile) * kWgTP + pix) * g.Cout + oc0 + p * 8);        \
+    }
+#define NF_LOAD_X(i)                                                                      \
+    {                                                                                     \
+        px##i = make_uint4(0u, 0u, 0u, 0u);                                               \
+        if (plan[i] >= 0) {                                                               \
+            const int p = (tid + i * 256) & 7;                                            \
+            const int band = plan[i] >> 16, pr = (plan[i] >> 8) & 255, pc = plan[i] & 255; \
+            const int grow = ((ftile * kWgTP) >> g.logW) + band * g.RI;                   \
+            const int img = grow >> g.logH, y0 = grow & (g.H - 1);                        \
+            const int yy = y0 + pr - 1, xx = pc - 1;                                      \
+            if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)                               \
+                px##i = *reinterpret_cast<const uint4*>(                                  \
+                    x + static_cast<long>((img * g.H + yy) * g.W + xx) * g.Cin + ic0 + p * 8); \
+        }                                                                                 \
+    }
+#define NF_STORE_DY(i)                                                                    \
+    {                                                                                     \
+        const int q = tid + i * 256, pix = q >> 3, p = q & 7;                             \
+        *reinterpret_cast<uint4*>(s_dy + pix * kWgPitch + p * 16) = pdy##i;               \
+    }
+#define NF_STORE_X(i)                                                                     \
+    if (plan[i] >= 0) {                                                                   \
+        const int q = tid + i * 256, pp = q >> 3, p = q & 7;                              \
+        *reinterpret_cast<uint4*>(s_x + pp * kWgPitch + p * 16) = px##i;                  \
+    }
+    NF_DY_LIST(NF_LOAD_DY)
+    NF_X_LIST(NF_LOAD_X)
     for (int it = 0; it < nit; ++it) {
-        const int tile = blockIdx.x * nit + it;
-        const int row0 = (tile * kWgTP) >> g.logW;
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + i * 256, px = q >> 3, p = q & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(
-                dy + (static_cast<long>(tile) * kWgTP + px) * g.Cout + oc0 + p * 8);
-            *reinterpret_cast<uint4*>(s_dy + px * kWgPitch + p * 16) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            if (plan[i] >= 0) {
-                const int q = tid + i * 256, pp = q >> 3, p = q & 7;
-                const int band = plan[i] >> 16, pr = (plan[i] >> 8) & 255, pc = plan[i] & 255;
-                const int grow = row0 + band * g.RI;
-                const int img = grow >> g.logH, y0 = grow & (g.H - 1);
-                const int yy = y0 + pr - 1, xx = pc - 1;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
-                    v = *reinterpret_cast<const uint4*>(
-                        x + static_cast<long>((img * g.H + yy) * g.W + xx) * g.Cin + ic0 + p * 8);
-                *reinterpret_cast<uint4*>(s_x + pp * kWgPitch + p * 16) = v;
-            }
+        NF_DY_LIST(NF_STORE_DY)
+        NF_X_LIST(NF_STORE_X)
+        if (it + 1 < nit) {
+            ftile = blockIdx.x * nit + it + 1;
+            NF_DY_LIST(NF_LOAD_DY)
+            NF_X_LIST(NF_LOAD_X)
         }
         __syncthreads();
+#undef NF_DY_LIST
+#undef NF_X_LIST
+#undef NF_DECL_DY
+#undef NF_DECL_X
+#undef NF_LOAD_DY
+#undef NF_LOAD_X
+#undef NF_STORE_DY
+#undef NF_STORE_X
 #pragma unroll 1
         for (int ks = 0; ks < kWgTP / 16; ++ks) {
             const bf16x8 Afr = load_tr_frag(s_dy, kWgPitch, ks * 16, ob * 32, lane);
@@ -338,31 +372,46 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
             }
         }
     }
-    float* slab = part + static_cast<long>(blockIdx.x) * g.Cout * 9 * g.Cin;
+    bf16* slab = part + static_cast<long>(blockIdx.x) * g.Cout * 9 * g.Cin;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oc = oc0 + ob * 32 + acc_row(r, lane);
-            slab[(static_cast<long>(oc) * 9 + t) * g.Cin + ic0 + ib * 32 + (lane & 31)] = acc[t][r];
+            slab[(static_cast<long>(oc) * 9 + t) * g.Cin + ic0 + ib * 32 + (lane & 31)] =
+                f2bf(acc[t][r]);
         }
 }
 
-// dw[i] = sum over slabs, four consecutive elements per thread
+// dw[i] = sum over slabs in a fixed order.  A workgroup owns 64 groups of four
+// consecutive elements; its four waves each sum every fourth slab (so that few,
+// long columns still spread over the chip) and combine through LDS.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ dw, long n4, int slabs) {
-    const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const float4* p = reinterpret_cast<const float4*>(part) + i;
+wgrad_reduce_kernel(const bf16* __restrict__ part, bf16* __restrict__ dw, long n4, int slabs) {
+    __shared__ float4 red[3][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long i = static_cast<long>(blockIdx.x) * 64 + lane;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const bf16x4* p = reinterpret_cast<const bf16x4*>(part) + i;
 #pragma unroll 4
-    for (int s = 0; s < slabs; ++s) {
-        const float4 v = p[static_cast<long>(s) * n4];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        for (int s = grp; s < slabs; s += 4) {
+            const bf16x4 v = p[static_cast<long>(s) * n4];
+            a.x += bf2f(v[0]); a.y += bf2f(v[1]); a.z += bf2f(v[2]); a.w += bf2f(v[3]);
+        }
     }
-    bf16x4 o;
-    o[0] = f2bf(a.x); o[1] = f2bf(a.y); o[2] = f2bf(a.z); o[3] = f2bf(a.w);
-    *reinterpret_cast<bf16x4*>(dw + i * 4) = o;
+    if (grp > 0) red[grp - 1][lane] = a;
+    __syncthreads();
+    if (grp == 0 && i < n4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 v = red[k][lane];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        bf16x4 o;
+        o[0] = f2bf(a.x); o[1] = f2bf(a.y); o[2] = f2bf(a.z); o[3] = f2bf(a.w);
+        *reinterpret_cast<bf16x4*>(dw + i * 4) = o;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -479,7 +528,7 @@ int nf_conv3x3_flip_weights(const void* w, void* wt, int Cin, int Cout, hipStrea
 // make this many workgroups (default 192).
 void nf_conv3x3_set_wgrad_min_workgroups(int n) { g_wgrad_min_wgs = n < 1 ? 1 : n; }
 
-// floats of workspace nf_conv3x3_wgrad needs
+// bf16 elements of workspace nf_conv3x3_wgrad needs
 long nf_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
     const long M = static_cast<long>(B) * H * W;
     if (M % kWgTP != 0 || Cin % 64 != 0 || Cout % 64 != 0) return -1;
@@ -488,7 +537,7 @@ long nf_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
 }
 
 // dw[Cout][3][3][Cin] (bf16) = weight gradient of the convolution above.
-int nf_conv3x3_wgrad(const void* x, const void* dy, void* dw, float* workspace, int B, int H,
+int nf_conv3x3_wgrad(const void* x, const void* dy, void* dw, void* workspace, int B, int H,
                      int W, int Cin, int Cout, hipStream_t s) {
     ConvGeo g;
     if (!make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g)) return -1;
@@ -500,10 +549,12 @@ int nf_conv3x3_wgrad(const void* x, const void* dy, void* dw, float* workspace, 
     static const int lds_ok = set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), kWgLds);
     if (lds_ok != 0) return -20;
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), kWgLds, s,
-                       static_cast<const bf16*>(x), static_cast<const bf16*>(dy), workspace, g, nit);
+                       static_cast<const bf16*>(x), static_cast<const bf16*>(dy),
+                       static_cast<bf16*>(workspace), g, nit);
     const long n4 = static_cast<long>(Cout) * 9 * Cin / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)),
-                       dim3(256), 0, s, workspace, static_cast<bf16*>(dw), n4, slabs);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((n4 + 63) / 64)),
+                       dim3(256), 0, s, static_cast<const bf16*>(workspace), static_cast<bf16*>(dw),
+                       n4, slabs);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -101,10 +101,10 @@ def conv3x3_input_grad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 def conv3x3_weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     b, c_in, h, wd = x.shape
     c_out = dy.shape[1]
-    floats = int(_fn("nf_conv3x3_wgrad_workspace")(b, h, wd, c_in, c_out))
-    if floats <= 0:
+    elems = int(_fn("nf_conv3x3_wgrad_workspace")(b, h, wd, c_in, c_out))
+    if elems <= 0:
         raise RuntimeError("conv3x3 weight gradient: unsupported shape")
-    ws = torch.empty(floats, dtype=torch.float32, device=x.device)
+    ws = torch.empty(elems, dtype=torch.bfloat16, device=x.device)
     dw = torch.empty((c_out, c_in, 3, 3), dtype=torch.bfloat16, device=x.device, memory_format=CL)
     library.check(
         _fn("nf_conv3x3_wgrad")(_p(x), _p(dy), _p(dw), _p(ws), b, h, wd, c_in, c_out,
@@ -114,9 +114,17 @@ def conv3x3_weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dw
 
 
-# The weight gradient of the library (autotuned) is still faster than
-# conv3x3_weight_grad for the ResNet shapes, so the autograd op uses it by default.
-NATIVE_WEIGHT_GRAD = os.environ.get("NANOFED_CONV_NATIVE_WGRAD", "0") == "1"
+# Weight gradient: the hand-written kernel wins for the ResNet stages with images of
+# 8x8 and larger (26 / 24 / 24 us against 29 / 26 / 26 for the autotuned library at
+# batch 64), the library for the 4x4 stage (22 against 26 us).  "auto" picks by image
+# size; NANOFED_CONV_WGRAD=native|library forces one.
+WEIGHT_GRAD = os.environ.get("NANOFED_CONV_WGRAD", "auto")
+
+
+def use_native_weight_grad(x: torch.Tensor) -> bool:
+    if WEIGHT_GRAD == "auto":
+        return x.shape[2] * x.shape[3] >= 64
+    return WEIGHT_GRAD == "native"
 
 
 def library_weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -140,7 +148,8 @@ class _Conv3x3(torch.autograd.Function):
         dx = conv3x3_input_grad(dy, w) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = conv3x3_weight_grad(x, dy) if NATIVE_WEIGHT_GRAD else library_weight_grad(x, dy, w)
+            dw = (conv3x3_weight_grad(x, dy) if use_native_weight_grad(x)
+                  else library_weight_grad(x, dy, w))
         return dx, dw
 
 
