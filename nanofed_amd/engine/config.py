@@ -54,6 +54,12 @@ class EngineConfig:
     # torch trainer: train the clients of a GPU concurrently, one HIP stream each
     # (their kernels are too small to fill the chip one client at a time)
     client_streams: bool = True
+    # how many streams the clients of a GPU share (a process has 4 hardware queues
+    # by default; more streams than queues gain nothing)
+    client_stream_count: int = 4
+    # native GPT-2 trainer: concurrent client steps ("lanes", at most 2; see the
+    # note in GPT2NativeTrainer.__init__ before raising this from 1)
+    gpt2_lanes: int = 1
     reduce_algo: str = "auto"  # auto | allreduce | rs_ag
     drop_last: bool = False
     # native MNIST kernels: conv2 workgroups per image (1 or 3); 0 = choose from

@@ -112,18 +112,19 @@ class GPT2NativeTrainer(GroupTrainer):
         # process twice (no GPU fault), the second time with the one stream-K GEMM
         # of the step - the LM-head forward, whose workgroups wait for each other
         # through memory - serialised across lanes, so the cause is not understood.
-        # Lanes are therefore opt-in (NANOFED_GPT2_LANES=2), never more than two,
-        # and only for the step shape whose kernel trace was inspected (GPT-2
+        # Lanes are therefore opt-in (EngineConfig.gpt2_lanes or NANOFED_GPT2_LANES=2),
+        # never more than two, and only for the step shape whose kernel trace was inspected (GPT-2
         # small, 4096 rows per step, full batches); the default is one lane.
-        if LANES > 2:
-            raise DeviceError("NANOFED_GPT2_LANES: more than two lanes hung the GPU queue; use 1 or 2")
+        want = max(LANES, cfg.gpt2_lanes)
+        if want > 2:
+            raise DeviceError("more than two GPT-2 lanes hung the GPU queue; use 1 or 2")
         lanes = 1
         rows = cfg.batch_size * cfg.seq_len
         profiled = (model_cfg.n_embd, model_cfg.vocab_size, rows) == (768, 50257, 4096)
         full_batches = all(sz % cfg.batch_size == 0 for sz in shards.sizes)
         if (cfg.client_streams and self.device.type == "cuda" and G > 1 and profiled
                 and full_batches):
-            lanes = min(G, max(LANES, 1))
+            lanes = min(G, max(want, 1))
         self.lanes = max(1, lanes)
         self._lm_head_done = torch.cuda.Event() if self.lanes > 1 else None
         self._grads = [torch.zeros(n, dtype=BF16, device=self.device) for _ in range(self.lanes)]

@@ -129,9 +129,9 @@ class TorchGroupTrainer(GroupTrainer):
         self._streams: list[torch.cuda.Stream] | None = None
         if (cfg.client_streams and self.device.type == "cuda" and len(pool) > 1
                 and shards.kind == "image"):
-            # more streams than hardware queues (4 per process by default) bring
-            # nothing; NANOFED_CLIENT_STREAMS overrides the count for experiments
-            ns = min(len(pool), int(os.environ.get("NANOFED_CLIENT_STREAMS", "4")))
+            # NANOFED_CLIENT_STREAMS overrides the configured count for experiments
+            ns = int(os.environ.get("NANOFED_CLIENT_STREAMS", cfg.client_stream_count))
+            ns = max(1, min(len(pool), ns))
             base = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
             self._streams = [base[k % ns] for k in range(len(pool))]
         if self._channels_last:
