@@ -279,18 +279,23 @@ int nf_bn_workspace_floats(int C) { return kMaxBlocks * 2 * C; }
 
 // stats: 2*C floats (mean, 1/std) kept for the backward pass.  running_* may
 // be null.  res may be null.  y may not alias x when relu is set (the backward
-// pass reads both).
+// pass reads both).  pre_blocks > 0: workspace already holds that many rows of
+// per-channel partial sums [block][2][C] of x and x^2 (written by the kernel that
+// produced x), so the pass over x that computes them is skipped.
 int nf_bn_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
               float* running_mean, float* running_var, float* stats, float* workspace, long R,
-              int C, int relu, float momentum, float eps, hipStream_t s) {
+              int C, int relu, float momentum, float eps, int pre_blocks, hipStream_t s) {
     const int lpr = lanes_per_row(C);
-    if (lpr == 0 || R <= 0) return -1;
+    if (lpr == 0 || R <= 0 || pre_blocks < 0) return -1;
     if (!al16(x) || !al16(y) || (res != nullptr && !al16(res))) return -2;
-    const int nb = blocks_for(R, lpr);
-    const long rpb = (R + nb - 1) / nb;
-    const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), lds, s,
-                       static_cast<const bf16*>(x), workspace, R, C, lpr, rpb);
+    int nb = pre_blocks;
+    if (pre_blocks == 0) {
+        nb = blocks_for(R, lpr);
+        const long rpb = (R + nb - 1) / nb;
+        const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), lds, s,
+                           static_cast<const bf16*>(x), workspace, R, C, lpr, rpb);
+    }
     const float unbias = R > 1 ? static_cast<float>(R) / static_cast<float>(R - 1) : 1.f;
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace,
                        stats, running_mean, running_var, nb, C, 1.f / static_cast<float>(R),

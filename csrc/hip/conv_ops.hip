@@ -40,6 +40,7 @@ namespace {
 constexpr int kBRows = 64 * 9;            // weight rows of an output-channel tile
 constexpr int kMaxAPieces = 5;            // 16-byte patch pieces per thread and chunk
 constexpr int kRedBytes = 4 * 4 * 16 * 64 * 4;  // accumulators of four waves
+constexpr int kColsumBytes = 4 * 2 * 2 * 32 * 4;  // column-sum staging behind them
 
 // forward staging for chunks of CH input channels
 template <int CH>
@@ -86,8 +87,8 @@ __device__ __forceinline__ int patch_index(const ConvGeo& g, int m) {
 template <int PXW, int KSW, int CH>
 __global__ void __launch_bounds__(256)
 conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
-                   ConvGeo g) {
-    static_assert(PXW * KSW == 4, "four waves");
+                   float* __restrict__ colsum, ConvGeo g) {
+    static_assert(PXW * KSW == 4 && KSW > 1, "four waves, k-split");
     using St = FwdStage<CH>;
     constexpr int TP = 64 * PXW;
     constexpr int kPitch = St::kPitch, kPieces = St::kPieces;
@@ -210,23 +211,51 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
         __syncthreads();
     }
     constexpr int kBlocksPerWave = 4 / KSW;
+    float cs1[kBlocksPerWave], cs2[kBlocksPerWave];  // column sums of y and y^2 (as stored)
 #pragma unroll
     for (int j = 0; j < kBlocksPerWave; ++j) {
         const int blk = kw * kBlocksPerWave + j, mb = blk >> 1, nb = blk & 1;
         const long pix0 = static_cast<long>(tile) * TP + pw * 64 + mb * 32;
         bf16* dst = y + pix0 * g.Cout + oc0 + nb * 32 + (lane & 31);
+        cs1[j] = 0.f;
+        cs2[j] = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v;
-            if constexpr (KSW > 1) {
-                v = 0.f;
+            float v = 0.f;
 #pragma unroll
-                for (int k2 = 0; k2 < KSW; ++k2)
-                    v += red[(((k2 * PXW + pw) * 4 + blk) * 16 + r) * 64 + lane];
-            } else {
-                v = acc[j >> 1][j & 1][r];
+            for (int k2 = 0; k2 < KSW; ++k2)
+                v += red[(((k2 * PXW + pw) * 4 + blk) * 16 + r) * 64 + lane];
+            const bf16 vb = f2bf(v);
+            dst[static_cast<long>(acc_row(r, lane)) * g.Cout] = vb;
+            const float vf = bf2f(vb);
+            cs1[j] += vf;
+            cs2[j] = fmaf(vf, vf, cs2[j]);
+        }
+    }
+    // Per-channel sums over the tile's pixels, for a BatchNorm that follows:
+    // colsum[tile][0][oc] = sum y, colsum[tile][1][oc] = sum y^2.
+    if (colsum != nullptr) {
+        float* cs = reinterpret_cast<float*>(smem + kRedBytes);  // [wave][j][2][32]
+#pragma unroll
+        for (int j = 0; j < kBlocksPerWave; ++j) {
+            cs1[j] += __shfl_xor(cs1[j], 32, 64);
+            cs2[j] += __shfl_xor(cs2[j], 32, 64);
+            if (lane < 32) {
+                cs[((wave * kBlocksPerWave + j) * 2 + 0) * 32 + lane] = cs1[j];
+                cs[((wave * kBlocksPerWave + j) * 2 + 1) * 32 + lane] = cs2[j];
             }
-            dst[static_cast<long>(acc_row(r, lane)) * g.Cout] = f2bf(v);
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int stat = tid >> 6, oc = tid & 63, nb = oc >> 5, n = oc & 31;
+            float total = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+                for (int j = 0; j < kBlocksPerWave; ++j)
+                    if ((((wv / PXW) * kBlocksPerWave + j) & 1) == nb)
+                        total += cs[((wv * kBlocksPerWave + j) * 2 + stat) * 32 + n];
+            colsum[(static_cast<long>(tile) * 2 + stat) * g.Cout + oc0 + oc] = total;
         }
     }
 }
@@ -483,9 +512,17 @@ int nf_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
     return make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g) ? 1 : 0;
 }
 
+// Pixel tiles of the forward kernel for this shape: the number of partial rows
+// nf_conv3x3_fwd writes into colsum.
+int nf_conv3x3_fwd_tiles(int B, int H, int W, int Cout) {
+    return static_cast<int>(static_cast<long>(B) * H * W / fwd_tile_pixels(B, H, W, Cout));
+}
+
 // y[B][H][W][Cout] = conv3x3(x[B][H][W][Cin], w[Cout][3][3][Cin]), bf16.
-int nf_conv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin,
-                   int Cout, hipStream_t s) {
+// colsum (may be null): [tiles][2][Cout] floats, per-tile sums of y and y^2 over the
+// tile's pixels for every channel (what a following BatchNorm needs).
+int nf_conv3x3_fwd(const void* x, const void* w, void* y, float* colsum, int B, int H, int W,
+                   int Cin, int Cout, hipStream_t s) {
     const int tp = fwd_tile_pixels(B, H, W, Cout);
     ConvGeo g;
     if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
@@ -503,15 +540,17 @@ int nf_conv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, i
     if (tp == 128) {
         using St = FwdStage<32>;
         int lds = St::kBBytes + g.np * St::kPitch;
-        if (lds < kRedBytes) lds = kRedBytes;
+        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
         if (lds > kLdsCap) return -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32>), grid, dim3(256), lds, s, xp, wp, yp, g);
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32>), grid, dim3(256), lds, s, xp, wp, yp, colsum,
+                           g);
     } else {
         using St = FwdStage<64>;
         int lds = St::kBBytes + g.np * St::kPitch;
-        if (lds < kRedBytes) lds = kRedBytes;
+        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
         if (lds > kLdsCap) return -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64>), grid, dim3(256), lds, s, xp, wp, yp, g);
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64>), grid, dim3(256), lds, s, xp, wp, yp, colsum,
+                           g);
     }
     return static_cast<int>(hipGetLastError());
 }

@@ -35,12 +35,14 @@ class BasicBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # BatchNorm, the residual add and the ReLU are one fused op on the GPU; the
         # stride-1 3x3 convolutions run on the hand-written MFMA kernels there
-        out = batch_norm_act(self.bn1, conv2d(self.conv1, x))
+        y, sums = conv2d(self.conv1, x, with_sums=True)  # sums: BatchNorm's statistics
+        out = batch_norm_act(self.bn1, y, partials=sums)
         if len(self.shortcut) == 0:
             short = x
         else:
             short = batch_norm_act(self.shortcut[1], self.shortcut[0](x), relu=False)
-        return batch_norm_act(self.bn2, conv2d(self.conv2, out), residual=short)
+        y, sums = conv2d(self.conv2, out, with_sums=True)
+        return batch_norm_act(self.bn2, y, residual=short, partials=sums)
 
 
 class ResNet18(nn.Module):

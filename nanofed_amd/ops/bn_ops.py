@@ -24,7 +24,7 @@ P, L, I, FL = c_void_p, c_long, c_int, c_float
 _SIGS = {
     "nf_bn_supported": ([I], I),
     "nf_bn_workspace_floats": ([I], I),
-    "nf_bn_fwd": ([P, P, P, P, P, P, P, P, P, L, I, I, FL, FL, P], I),
+    "nf_bn_fwd": ([P, P, P, P, P, P, P, P, P, L, I, I, FL, FL, I, P], I),
     "nf_bn_bwd": ([P, P, P, P, P, P, P, P, P, P, L, I, I, P], I),
 }
 _fns: dict[str, object] = {}
@@ -66,18 +66,27 @@ def fused_path_applies(x: torch.Tensor, training: bool, residual: torch.Tensor |
 
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, relu, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, relu, momentum, eps,
+                partials):
         n, c, h, w = x.shape
         rows = n * h * w
         dev = x.device
         y = torch.empty_like(x)  # channels-last like x
         stats = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        ws = torch.empty(int(_fn("nf_bn_workspace_floats")(c)), dtype=torch.float32, device=dev)
+        if partials is not None:  # [blocks, 2, C] sums of x and x^2 from x's producer
+            if partials.dtype != torch.float32 or partials.shape[1:] != (2, c) or (
+                    not partials.is_contiguous()):
+                raise ValueError("partial sums must be contiguous float32 [blocks, 2, C]")
+            ws, pre = partials, partials.shape[0]
+        else:
+            ws = torch.empty(int(_fn("nf_bn_workspace_floats")(c)), dtype=torch.float32,
+                             device=dev)
+            pre = 0
         gamma, beta = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         library.check(
             _fn("nf_bn_fwd")(_p(x), _p(residual), _p(y), _p(gamma), _p(beta), _p(running_mean),
                              _p(running_var), _p(stats), _p(ws), rows, c, int(relu), momentum,
-                             eps, library.stream_ptr(dev)),
+                             eps, pre, library.stream_ptr(dev)),
             "bn_fwd",
         )
         ctx.save_for_backward(x, y, stats, gamma)
@@ -104,12 +113,16 @@ class _BatchNormAct(torch.autograd.Function):
                              library.stream_ptr(dev)),
             "bn_bwd",
         )
-        return dx, dgamma, dbeta, None, None, dres, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
 def batch_norm_act(bn: nn.BatchNorm2d, x: torch.Tensor, residual: torch.Tensor | None = None,
-                   relu: bool = True) -> torch.Tensor:
+                   relu: bool = True, partials: torch.Tensor | None = None) -> torch.Tensor:
     """``relu(batch_norm(x) + residual)`` with ``bn``'s parameters and buffers.
+
+    ``partials`` ([blocks, 2, C] float32 sums of x and x^2 over disjoint pixel
+    ranges, as ``conv_ops.conv2d(..., with_sums=True)`` returns them) spares the
+    statistics pass over ``x``; it is ignored on the fallback path.
 
     A trainer that counts optimisation steps itself sets ``bn.defer_batch_count``
     and adds the count to ``num_batches_tracked`` once per round, which saves one
@@ -121,7 +134,7 @@ def batch_norm_act(bn: nn.BatchNorm2d, x: torch.Tensor, residual: torch.Tensor |
             with torch.no_grad():
                 bn.num_batches_tracked.add_(1)
         return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   residual, relu, float(bn.momentum), float(bn.eps))
+                                   residual, relu, float(bn.momentum), float(bn.eps), partials)
     out = bn(x)
     if residual is not None:
         out = out + residual

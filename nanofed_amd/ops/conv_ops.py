@@ -24,7 +24,8 @@ from . import library
 P, L, I = c_void_p, c_long, c_int
 _SIGS = {
     "nf_conv3x3_supported": ([I, I, I, I, I], I),
-    "nf_conv3x3_fwd": ([P, P, P, I, I, I, I, I, P], I),
+    "nf_conv3x3_fwd": ([P, P, P, P, I, I, I, I, I, P], I),
+    "nf_conv3x3_fwd_tiles": ([I, I, I, I], I),
     "nf_conv3x3_flip_weights": ([P, P, I, I, P], I),
     "nf_conv3x3_wgrad_workspace": ([I, I, I, I, I], L),
     "nf_conv3x3_wgrad": ([P, P, P, P, I, I, I, I, I, P], I),
@@ -75,17 +76,23 @@ def native_path_applies(conv: nn.Conv2d, x: torch.Tensor) -> bool:
     return c == conv.in_channels and shape_supported(b, h, w, c, conv.out_channels)
 
 
-def conv3x3_forward(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """x: [B, Cin, H, W], w: [Cout, Cin, 3, 3], both bf16 in channels-last storage."""
+def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, with_sums: bool = False):
+    """x: [B, Cin, H, W], w: [Cout, Cin, 3, 3], both bf16 in channels-last storage.
+    ``with_sums``: also return [tiles, 2, Cout] float32 per-channel sums of the
+    output and its square over disjoint pixel tiles (for a following BatchNorm)."""
     b, c_in, h, wd = x.shape
     c_out = w.shape[0]
     y = torch.empty((b, c_out, h, wd), dtype=torch.bfloat16, device=x.device, memory_format=CL)
+    sums = None
+    if with_sums:
+        tiles = int(_fn("nf_conv3x3_fwd_tiles")(b, h, wd, c_out))
+        sums = torch.empty((tiles, 2, c_out), dtype=torch.float32, device=x.device)
     library.check(
-        _fn("nf_conv3x3_fwd")(_p(x), _p(w), _p(y), b, h, wd, c_in, c_out,
-                              library.stream_ptr(x.device)),
+        _fn("nf_conv3x3_fwd")(_p(x), _p(w), _p(y), _p(sums) if sums is not None else c_void_p(0),
+                              b, h, wd, c_in, c_out, library.stream_ptr(x.device)),
         "conv3x3_fwd",
     )
-    return y
+    return (y, sums) if with_sums else y
 
 
 def conv3x3_input_grad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -135,13 +142,17 @@ def library_weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor) -> t
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, with_sums):
         w = weight.detach().contiguous(memory_format=CL)
         ctx.save_for_backward(x, w)
-        return conv3x3_forward(x, w)
+        if not with_sums:
+            return conv3x3_forward(x, w)
+        y, sums = conv3x3_forward(x, w, with_sums=True)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, w = ctx.saved_tensors
         if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=CL):
             dy = dy.to(torch.bfloat16).contiguous(memory_format=CL)
@@ -150,11 +161,14 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = (conv3x3_weight_grad(x, dy) if use_native_weight_grad(x)
                   else library_weight_grad(x, dy, w))
-        return dx, dw
+        return dx, dw, None
 
 
-def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """``conv(x)``; on the hand-written kernels when they cover the case."""
+def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_sums: bool = False):
+    """``conv(x)``; on the hand-written kernels when they cover the case.
+    ``with_sums=True`` returns ``(y, sums)``: ``sums`` are the per-channel partial
+    sums of ``conv3x3_forward`` on the kernel path and ``None`` otherwise."""
     if native_path_applies(conv, x):
-        return _Conv3x3.apply(x, conv.weight.to(torch.bfloat16))
-    return conv(x)
+        return _Conv3x3.apply(x, conv.weight.to(torch.bfloat16), with_sums)
+    y = conv(x)
+    return (y, None) if with_sums else y

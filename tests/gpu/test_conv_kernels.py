@@ -23,7 +23,8 @@ SHAPES = [
 
 
 def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
-    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12))
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
 
 
 @pytest.fixture(scope="module")
@@ -109,3 +110,42 @@ def test_unsupported_cases_use_the_module(ops):
     assert not ops.native_path_applies(conv1, x3)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert ops.conv2d(conv, x).shape == (4, 64, 8, 8)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:5])
+def test_channel_sums_of_the_output(ops, shape):
+    b, h, w, c_in, c_out = shape
+    gen = torch.Generator(device="cuda").manual_seed(99 + c_in)
+    x = torch.randn(b, c_in, h, w, device="cuda", generator=gen).to(torch.bfloat16)
+    x = x.contiguous(memory_format=CL)
+    wt = (torch.randn(c_out, c_in, 3, 3, device="cuda", generator=gen) / (3 * c_in**0.5))
+    wt = wt.to(torch.bfloat16).contiguous(memory_format=CL)
+    y_plain = ops.conv3x3_forward(x, wt)
+    y, sums = ops.conv3x3_forward(x, wt, with_sums=True)
+    assert torch.equal(y, y_plain)
+    assert sums.shape[1:] == (2, c_out) and sums.dtype == torch.float32
+    yf = y.float()
+    ref1 = yf.sum(dim=(0, 2, 3))
+    ref2 = (yf * yf).sum(dim=(0, 2, 3))
+    torch.testing.assert_close(sums[:, 0].sum(0), ref1, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(sums[:, 1].sum(0), ref2, rtol=1e-4, atol=1e-2)
+
+
+def test_batchnorm_takes_the_convolution_sums(ops):
+    from nanofed_amd.ops.bn_ops import batch_norm_act
+
+    torch.manual_seed(4)
+    conv = nn.Conv2d(128, 128, 3, 1, 1, bias=False).cuda()
+    bns = [nn.BatchNorm2d(128).cuda().train() for _ in range(2)]
+    x = torch.randn(64, 128, 16, 16, device="cuda").to(torch.bfloat16).contiguous(memory_format=CL)
+    res = torch.randn_like(x)
+    y, sums = ops.conv2d(conv, x, with_sums=True)
+    assert sums is not None
+    a = batch_norm_act(bns[0], y, residual=res, partials=sums)
+    b = batch_norm_act(bns[1], y, residual=res)
+    torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(bns[0].running_mean, bns[1].running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bns[0].running_var, bns[1].running_var, rtol=1e-4, atol=1e-5)
+    # gradients flow through both ops
+    a.float().square().mean().backward()
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
