@@ -100,6 +100,8 @@ struct MnistCtx {
     float dp_clip, dp_noise_std;  // per-sample L2 bound C, noise std on the SUM (sigma * C)
     float* dp_normsq;       // [G][B][4] squared per-sample gradient norms: fc2, conv1, conv2.weight, -
     float* dp_rowscale;     // [G][B] clip factor of every sample
+    int ragged;             // 1: some client runs out of batches before the others
+    int cur_step;           // step of the launch (filled in by nf_mnist_stage)
 };
 
 }  // extern "C"
@@ -110,12 +112,20 @@ constexpr int kA1Pix = 676, kA1C = 32, kP2Pix = 144, kC2 = 64, kFc1K = 9216;
 constexpr int kHeadPart = 1440, kConv2Part = 18432, kConv1Part = 320, kHeadRows = 8;
 constexpr int kFc1Tiles = 72;
 
+// With shards of unequal size a client can be out of batches while others still
+// train: every kernel of the step then skips that client's workgroups (the test is
+// on a kernel argument first, so equal shards pay nothing).
+__device__ __forceinline__ bool client_idle(const MnistCtx& c, int g) {
+    return c.ragged != 0 && c.nvalid[g * c.nvalid_stride + c.cur_step] == 0;
+}
+
 __device__ __forceinline__ unsigned long long client_seed(const MnistCtx& c, int g) {
     return c.seed + 0x9E3779B97F4A7C15ull * static_cast<unsigned long long>(c.client_base + g + 1);
 }
 
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off) {
+    if (client_idle(c, blockIdx.y)) return;
     const int b = blockIdx.x / c.conv1_split, part = blockIdx.x % c.conv1_split;
     const int g = blockIdx.y, tid = threadIdx.x;
     __shared__ float xs[784];
@@ -187,6 +197,7 @@ __device__ __forceinline__ int fwd_swz(int pixel, int col, int chunk) {
 }
 
 __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
+    if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / c.split, g = blockIdx.y, tid = threadIdx.x;
     const int band0 = c.split == 1 ? 0 : blockIdx.x - b * c.split;
@@ -312,6 +323,7 @@ constexpr int kFc1Pitch = kFc1KC * 2 + 16;                // 592
 constexpr int kFc1FwdLds = (128 + 64) * kFc1Pitch;        // 113664
 
 __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
+    if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                     // [128 j][288 k]
     char* s_a = smem + 128 * kFc1Pitch;   // [64 b][288 k]
@@ -356,6 +368,7 @@ __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
 // ---------------------------------------------------------------------------
 // 8 batch rows per workgroup; thread = (row r, 4 consecutive hidden units).
 __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int step) {
+    if (client_idle(c, blockIdx.y)) return;
     const int hb = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     __shared__ float h1s[kHeadRows][132];
     __shared__ float dm[kHeadRows][132];
@@ -504,6 +517,7 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
 constexpr int kTrPitch128 = 320;  // 256 B of data + 64 B: 4 consecutive k rows hit distinct banks
 
 __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
+    if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [128 j][128 k'] pitch 320
     const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
@@ -572,7 +586,7 @@ __device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int 
     char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31;
-    if (c.fuse_sgd && c.nvalid[g * c.nvalid_stride + step] == 0) return;
+    if (client_idle(c, g) || (c.fuse_sgd && c.nvalid[g * c.nvalid_stride + step] == 0)) return;
     const bf16* dh = c.dh1 + static_cast<long>(g) * c.B * 128;
     const bf16* p2 = c.p2 + static_cast<long>(g) * c.B * kFc1K + tile * 128;
     for (int p = tid; p < 1024; p += 256) {
@@ -666,6 +680,7 @@ __device__ __forceinline__ int dg_swz(int pr, int pc, int part) {
 }
 
 __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off, int bx, int g) {
+    if (client_idle(c, g)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);       // normalised input image
     int* soff = reinterpret_cast<int*>(xs + 784);                     // a1 pixel -> offset in xs
@@ -849,6 +864,7 @@ constexpr int kWgA1Bytes = 260 * 64;          // 16640
 constexpr int kWgLds = kWgDaBytes + kWgA1Bytes;
 
 __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
+    if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_da = smem;               // [192 px][64 oc], pitch 192
     char* s_a1 = smem + kWgDaBytes;  // [260 px][32 c], pitch 64
@@ -954,6 +970,7 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
 // pixel sums of dp2) to the tile norms and writes the clip factor
 //   min(1, C / ||g_b||),  g_b = n * (gradient of the mean loss w.r.t. sample b).
 __global__ void __launch_bounds__(256) dp_scale_kernel(MnistCtx c, int step) {
+    if (client_idle(c, blockIdx.y)) return;
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ float red[3][4];
@@ -1025,6 +1042,7 @@ __device__ __forceinline__ float sum_slabs(const float* p, int count, long strid
 // fc1.weight update already happened in fc1_wgrad.
 template <bool kSgd>
 __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
+    if (client_idle(c, blockIdx.y)) return;
     __shared__ float part[4][64];
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1188,6 +1206,9 @@ int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
 int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
     const int rc = check_ctx(c);
     if (rc) return rc;
+    MnistCtx with_step = *c;
+    with_step.cur_step = step;
+    c = &with_step;
     const dim3 img_grid(c->B, c->G);
     const dim3 split_grid(c->B * c->split, c->G);
     switch (stage) {

@@ -83,6 +83,7 @@ class MnistCtx(ctypes.Structure):
         ("p_drop1", c_float), ("p_drop2", c_float),
         ("dp_clip", c_float), ("dp_noise_std", c_float),
         ("dp_normsq", c_void_p), ("dp_rowscale", c_void_p),
+        ("ragged", c_int), ("cur_step", c_int),
     ]
 
 
@@ -318,6 +319,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
             for s in range(steps):
                 nvalid[k, s] = min(B, n - s * B)
         self.buf.nvalid.copy_(nvalid)
+        # unequal shards: the kernels skip a client's workgroups once it has no batch left
+        self.buf.ctx.ragged = int(bool((nvalid == 0).any()))
         self.metrics = torch.zeros(G, METRIC_COLUMNS, dtype=torch.float32, device=self.device)
         self._graph: torch.cuda.CUDAGraph | None = None
         # staging table and (default-priority) side stream for the epoch shuffles
@@ -446,6 +449,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
                 nvalid[g, s] = hi - lo
             ev.idx.copy_(idx)
             ev.nvalid.copy_(nvalid)
+            ev.ctx.ragged = int(bool((nvalid == 0).any()))
             self._eval = ev
         ev = self._eval
         if ev.arena.data_ptr() != flat.data_ptr():

@@ -326,3 +326,32 @@ def test_native_engine_learns_and_evaluates():
     with torch.no_grad():
         acc = (model(ex).argmax(1) == ey).float().mean()
     assert float(acc) == pytest.approx(ev["accuracy"], abs=0.02)
+
+
+def test_idle_clients_are_skipped_without_changing_the_result():
+    """Dirichlet shards: clients run out of batches at different steps.  Skipping an
+    idle client's workgroups (ctx.ragged) must give the bits of the run that lets
+    them compute results nobody uses."""
+    from nanofed_amd.engine import EngineConfig, FederatedEngine
+    from nanofed_amd.parallel import Communicator
+
+    outs = []
+    for skip in (True, False):
+        torch.cuda.set_device(0)
+        cfg = EngineConfig(model="mnist_cnn", num_clients=4, samples_per_client=200, batch_size=64,
+                           local_epochs=2, eval_samples=130, backend="native", seed=11,
+                           partition="dirichlet", dirichlet_alpha=0.3)
+        eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
+        steps = {eng.shards.steps_per_epoch(k) for k in range(4)}
+        assert len(steps) > 1, "the shards must be unequal for this test"
+        assert eng.trainer.buf.ctx.ragged == 1
+        if not skip:
+            eng.trainer.buf.ctx.ragged = 0
+        reps = eng.run(2)
+        ev = eng.evaluate()
+        outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reps], ev))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    # the evaluation sums batches with float atomics: equal up to the summation order
+    assert outs[0][2]["accuracy"] == outs[1][2]["accuracy"]
+    assert outs[0][2]["loss"] == pytest.approx(outs[1][2]["loss"], rel=1e-5)
