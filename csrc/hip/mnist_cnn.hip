@@ -62,7 +62,7 @@ struct MnistCtx {
     int train;            // 1: dropout active
     int client_base;      // global id of client 0 (dropout streams)
     int fuse_sgd;         // 1: fc1_wgrad applies fc1.weight's SGD update itself
-    int dp_pass;          // 0: plain SGD; 1: norm pass of DP-SGD; 2: clipped pass
+    int dp_pass;          // 0: plain SGD; 1: norm pass of DP-SGD; 2: clipped (re-weighting) pass
     int split;            // conv2 fwd/dgrad workgroups per image: 1 (whole image) or 3 (one band)
     int conv1_split;      // conv1 workgroups per image: 1, 2 or 4
     const uint8_t* images;  // [N][784]
@@ -100,6 +100,7 @@ struct MnistCtx {
     float dp_clip, dp_noise_std;  // per-sample L2 bound C, noise std on the SUM (sigma * C)
     float* dp_normsq;       // [G][B][4] squared per-sample gradient norms: fc2, conv1, conv2.weight, -
     float* dp_rowscale;     // [G][B] clip factor of every sample
+    float* dp_c2b;          // [G][B][64] conv2.bias gradient of every sample (DP-SGD)
     int ragged;             // 1: some client runs out of batches before the others
     int cur_step;           // step of the launch (filled in by nf_mnist_stage)
 };
@@ -950,7 +951,8 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
             for (int w = 0; w < 6; ++w) tot += red[w];
             c.dp_normsq[(static_cast<long>(g) * c.B + wg) * 4 + 2] = tot;
         }
-        return;
+        // the tile itself is kept: the clipped gradient is the clip-factor weighted sum
+        // of these per-sample tiles (finalize), not a second convolution pass
     }
     float* part = c.conv2_part + (static_cast<long>(g) * c.WPC + wg) * kConv2Part;
 #pragma unroll
@@ -1000,6 +1002,7 @@ __global__ void __launch_bounds__(256) dp_scale_kernel(MnistCtx c, int step) {
     if (tid < 64) {
         const float t = chs[0][tid] + chs[1][tid] + chs[2][tid] + chs[3][tid];
         cbsq = t * t;
+        c.dp_c2b[bi * 64 + tid] = t;
     }
     cbsq = wave_sum(cbsq);
     if (lane == 0) { red[0][wave] = p2sq; red[1][wave] = dhsq; red[2][wave] = cbsq; }
@@ -1035,6 +1038,22 @@ __device__ __forceinline__ float sum_slabs(const float* p, int count, long strid
     return s0 + s1;
 }
 
+// The same with a weight per slab (DP-SGD: slab b is sample b's gradient tile, the
+// weight its clip factor).
+__device__ __forceinline__ float sum_slabs_weighted(const float* p, const float* w, int count,
+                                                    long stride, int wave) {
+    const int lo = (count * wave) >> 2, hi = (count * (wave + 1)) >> 2;
+    float s0 = 0.f, s1 = 0.f;
+    int i = lo;
+#pragma unroll 4
+    for (; i + 1 < hi; i += 2) {
+        s0 = fmaf(w[i + 0], p[(i + 0) * stride], s0);
+        s1 = fmaf(w[i + 1], p[(i + 1) * stride], s1);
+    }
+    if (i < hi) s0 = fmaf(w[i], p[i * stride], s0);
+    return s0 + s1;
+}
+
 // 64 elements per workgroup, the slabs of each split over the four waves.
 // kSgd: also apply the SGD update of the element (every parameter except
 // fc1.weight is covered by exactly one thread), refresh its bf16 copies and
@@ -1055,17 +1074,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     const float* src = nullptr;
     int count = 0;
     long stride = 0;
+    // DP-SGD, clipped pass: the convolution tiles and the conv2.bias rows are per
+    // sample and unclipped (written by the norm pass); weight them here
+    const bool dp_weighted = c.dp_pass == 2;
+    bool weighted = false;
     if (e < kConv1Part) {
         count = c.B * c.split;
         stride = kConv1Part;
         src = c.conv1_part + static_cast<long>(g) * count * kConv1Part + e;
         dst = e < 288 ? c.off_c1w + e : c.off_c1b + e - 288;
+        weighted = dp_weighted;
     } else if (e < kConv1Part + kConv2Part) {
         const int e2 = e - kConv1Part;
         count = c.WPC;
         stride = kConv2Part;
         src = c.conv2_part + static_cast<long>(g) * c.WPC * kConv2Part + e2;
         dst = c.off_c2w + e2;
+        weighted = dp_weighted;
         const int oc = e2 / 288;
         w2t_at = (e2 - oc * 288) * 64 + oc;
     } else if (e < kConv1Part + kConv2Part + 64) {
@@ -1073,6 +1098,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
         count = kFc1Tiles;
         stride = 64;
         src = c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2;
+        if (dp_weighted) {
+            count = c.B;
+            src = c.dp_c2b + static_cast<long>(g) * c.B * 64 + e2;
+            weighted = true;
+        }
         dst = c.off_c2b + e2;
     } else if (e < kSmallTotal) {
         const int e3 = e - kConv1Part - kConv2Part - 64;
@@ -1086,7 +1116,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     }
     float* p = c.arena + g * c.arena_stride + (dst >= 0 ? dst : 0);
     const float pv = (kSgd && wave == 0) ? *p : 0.f;  // in flight during the sums
-    float s = src != nullptr ? sum_slabs(src, count, stride, wave) : 0.f;
+    float s = 0.f;
+    if (src != nullptr)
+        s = weighted ? sum_slabs_weighted(src, c.dp_rowscale + static_cast<long>(g) * c.B, count,
+                                          stride, wave)
+                     : sum_slabs(src, count, stride, wave);
     part[wave][lane] = s;
     __syncthreads();
     if (wave != 0) return;
@@ -1186,7 +1220,7 @@ inline int check_ctx(const MnistCtx* c) {
     if (c->n_arena % 64 != 0) return -5;
     if (c->dp_pass != 0 &&
         (c->WPC != c->B || c->split != 1 || c->fuse_sgd || c->dp_normsq == nullptr ||
-         c->dp_rowscale == nullptr))
+         c->dp_rowscale == nullptr || c->dp_c2b == nullptr))
         return -6;
     return 0;
 }
@@ -1254,9 +1288,10 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
 // One full optimisation step for all G clients.  With DP-SGD enabled
 // (ctx->dp_pass != 0) the backward runs twice: a norm pass that measures every
 // sample's gradient norm (conv tiles are per image; fc layers analytically),
-// then - after dp_scale turned the norms into clip factors - a pass whose
-// d(logits) rows are scaled by those factors, which scales each sample's whole
-// gradient.  Noise is added by sgd_pack.
+// then - after dp_scale turned the norms into clip factors - the head and the fc1
+// weight gradient run again with d(logits) rows scaled by those factors, while the
+// convolution gradients are the factor-weighted sums of the per-sample tiles the norm
+// pass left behind (finalize).  Noise is added by sgd_pack.
 int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
     if (c->dp_pass == 0) {
         if (c->fuse_sgd && c->G <= 2) {
@@ -1279,7 +1314,7 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     MnistCtx p = *c;
     static const int fwd[] = {0, 1, 2};
     static const int norm_pass[] = {3, 4, 6, 7, 11};
-    static const int clip_pass[] = {3, 4, 5, 6, 7, 8, 9};
+    static const int clip_pass[] = {3, 5, 8, 9};
     for (int st : fwd) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     p.dp_pass = 1;
     for (int st : norm_pass) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }

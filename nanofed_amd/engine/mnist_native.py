@@ -82,7 +82,7 @@ class MnistCtx(ctypes.Structure):
         ("lr", c_float), ("wd", c_float), ("mean", c_float), ("inv_std", c_float),
         ("p_drop1", c_float), ("p_drop2", c_float),
         ("dp_clip", c_float), ("dp_noise_std", c_float),
-        ("dp_normsq", c_void_p), ("dp_rowscale", c_void_p),
+        ("dp_normsq", c_void_p), ("dp_rowscale", c_void_p), ("dp_c2b", c_void_p),
         ("ragged", c_int), ("cur_step", c_int),
     ]
 
@@ -190,6 +190,7 @@ class NativeBuffers:
         self.conv2_part = z(G, wpc, 18432)
         self.dp_normsq = z(G, B, 4)
         self.dp_rowscale = z(G, B)
+        self.dp_c2b = z(G, B, 64)
         self.c2b_part = z(G, 72, 64)
         self.head_part = z(G, B // 8, 1440)
         self.metrics = z(G, 4)
@@ -234,6 +235,7 @@ class NativeBuffers:
         # something has to look at the whole gradient first (DP clipping)
         c.fuse_sgd = 1 if (train and fuse_sgd and dp is None) else 0
         c.dp_normsq, c.dp_rowscale = self.dp_normsq.data_ptr(), self.dp_rowscale.data_ptr()
+        c.dp_c2b = self.dp_c2b.data_ptr()
         if dp is not None and train:
             c.dp_pass = 2
             c.dp_clip = dp.max_gradient_norm
