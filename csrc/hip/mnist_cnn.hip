@@ -614,16 +614,45 @@ __device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int 
     if (c.fuse_sgd) {
         bf16* sh = c.shadow + g * c.shadow_stride + c.off_f1w + col;
         const float lr = c.lr, wd = c.wd;
+        // DP-SGD (clipped pass): Gaussian noise of std sigma*C/n on the mean gradient.
+        // One Philox block serves the four consecutive rows of an accumulator group.
+        const bool noisy = c.dp_pass == 2 && c.dp_noise_std > 0.f;
+        float nstd = 0.f;
+        unsigned long long nctr = 0ull;
+        if (noisy) {
+            nstd = c.dp_noise_std / static_cast<float>(c.nvalid[g * c.nvalid_stride + step]);
+            nctr = 2ull * c.step_counter[g] + 0x8000000000000001ull;
+        }
+        if (!noisy) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long o = static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K;
-                float pv = pa[o];
-                pv -= lr * fmaf(wd, pv, acc[mb][r]);
-                pa[o] = pv;
-                sh[o] = f2bf(pv);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const long o = static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K;
+                    float pv = pa[o];
+                    pv -= lr * fmaf(wd, pv, acc[mb][r]);
+                    pa[o] = pv;
+                    sh[o] = f2bf(pv);
+                }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float z[4];
+                    const unsigned long long rg = mb * 8 + 2 * rq + (lane >> 5);  // row / 4
+                    nf::philox_samples(client_seed(c, g), nctr, rg * kFc1K + col, 1, z);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = rq * 4 + k;
+                        const long o = static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K;
+                        float pv = pa[o];
+                        pv -= lr * fmaf(wd, pv, fmaf(nstd, z[k], acc[mb][r]));
+                        pa[o] = pv;
+                        sh[o] = f2bf(pv);
+                    }
+                }
+        }
     } else {
         float* gr = c.grad + g * c.grad_stride + c.off_f1w + col;
 #pragma unroll
@@ -1133,6 +1162,15 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     if (dst >= 0) gr[dst] = s;
     if (kSgd && nv > 0) {
         if (dst >= 0) {
+            if (c.dp_pass == 2 && c.dp_noise_std > 0.f) {
+                // the element's share of the noise block sgd_pack would draw for it
+                float z[4];
+                const unsigned long long nctr =
+                    2ull * c.step_counter[g] + 0x8000000000000000ull;
+                nf::philox_samples(client_seed(c, g), nctr,
+                                   static_cast<unsigned long long>(dst >> 2), 1, z);
+                s = fmaf(c.dp_noise_std / static_cast<float>(nv), z[dst & 3], s);
+            }
             const float v = pv - c.lr * fmaf(c.wd, pv, s);
             *p = v;
             const bf16 h = f2bf(v);
@@ -1219,7 +1257,7 @@ inline int check_ctx(const MnistCtx* c) {
     if (c->conv1_split != 1 && c->conv1_split != 2 && c->conv1_split != 4) return -8;
     if (c->n_arena % 64 != 0) return -5;
     if (c->dp_pass != 0 &&
-        (c->WPC != c->B || c->split != 1 || c->fuse_sgd || c->dp_normsq == nullptr ||
+        (c->WPC != c->B || c->split != 1 || c->dp_normsq == nullptr ||
          c->dp_rowscale == nullptr || c->dp_c2b == nullptr))
         return -6;
     return 0;
@@ -1271,7 +1309,7 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
         break;
     }
     case 12:
-        if (!c->fuse_sgd || c->dp_pass != 0) return -12;
+        if (!c->fuse_sgd || c->dp_pass == 1) return -12;
         hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step);
         break;
     case 9:
@@ -1314,12 +1352,17 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     MnistCtx p = *c;
     static const int fwd[] = {0, 1, 2};
     static const int norm_pass[] = {3, 4, 6, 7, 11};
-    static const int clip_pass[] = {3, 5, 8, 9};
+    static const int clip_unfused[] = {3, 5, 8, 9};
+    static const int clip_fused[] = {3, 5, 12};  // SGD + noise inside fc1_wgrad / finalize
     for (int st : fwd) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     p.dp_pass = 1;
     for (int st : norm_pass) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     p.dp_pass = 2;
-    for (int st : clip_pass) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+    if (p.fuse_sgd) {
+        for (int st : clip_fused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+    } else {
+        for (int st : clip_unfused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+    }
     return 0;
 }
 

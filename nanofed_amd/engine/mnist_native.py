@@ -231,9 +231,9 @@ class NativeBuffers:
         c.conv1_part, c.conv2_part, c.head_part = (
             self.conv1_part.data_ptr(), self.conv2_part.data_ptr(), self.head_part.data_ptr())
         c.c2b_part = self.c2b_part.data_ptr()
-        # the SGD update of fc1.weight is applied by fc1_wgrad itself unless
-        # something has to look at the whole gradient first (DP clipping)
-        c.fuse_sgd = 1 if (train and fuse_sgd and dp is None) else 0
+        # the SGD update of fc1.weight is applied by fc1_wgrad itself (DP-SGD: in the
+        # clipped pass, noise included; the other parameters by finalize)
+        c.fuse_sgd = 1 if (train and fuse_sgd) else 0
         c.dp_normsq, c.dp_rowscale = self.dp_normsq.data_ptr(), self.dp_rowscale.data_ptr()
         c.dp_c2b = self.dp_c2b.data_ptr()
         if dp is not None and train:
