@@ -41,7 +41,7 @@
 //                  fc1.weight's update it also applies SGD to every other
 //                  parameter and ends the step
 //   sgd_pack       SGD on the flat arena + bf16 shadow + transposed conv2 shadow
-//                  (unfused and DP-SGD steps)
+//                  (unfused steps, refresh of the copies after a broadcast)
 //
 // Storage ("native") layout of the parameters: conv2.weight [oc][kh][kw][c],
 // fc1.weight [j][(ph*12+pw)*64 + c]; everything else as in PyTorch.
