@@ -51,6 +51,10 @@ struct FwdStage {
     static constexpr int kBPerThread = kBRows * kPieces / 256;
     static constexpr int kMaxPatch = kMaxAPieces * 256 / kPieces;  // 320 (CH 32), 160 (CH 64)
     static constexpr int kSteps = 9 * CH / 16;        // MFMA k-steps per chunk
+    // data-gradient variant: weights staged [tap][CH oc][64 ic], ic contiguous
+    static constexpr int kTPitch = 64 * 2 + 32;       // transposing reads
+    static constexpr int kTBBytes = 9 * CH * kTPitch;
+    static_assert(9 * CH * 8 / 256 == kBPerThread, "same piece count in both layouts");
 };
 
 struct ConvGeo {
@@ -84,7 +88,12 @@ __device__ __forceinline__ int patch_index(const ConvGeo& g, int m) {
     return (band * (g.RI + 2) + r) * (g.W + 2) + xx;
 }
 
-template <int PXW, int KSW, int CH>
+// kDgrad: the launch computes a data gradient.  x is then dY, y is dX, g.Cin / g.Cout are
+// the layer's output / input channel counts, and w is the layer's weight as it is,
+// [g.Cin][9][g.Cout]: tap t of the launch uses the layer's tap 8 - t, and the weight
+// slice is staged with the reduction index (the layer's oc) as the slow dimension and
+// read through transposing LDS loads - no flipped copy of the weights is made.
+template <int PXW, int KSW, int CH, bool kDgrad>
 __global__ void __launch_bounds__(256)
 conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
                    float* __restrict__ colsum, ConvGeo g) {
@@ -94,8 +103,9 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     constexpr int kPitch = St::kPitch, kPieces = St::kPieces;
     constexpr int kLog = CH == 32 ? 2 : 3;  // log2(kPieces)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_b = smem;                 // [64 oc * 9 taps][CH ic]
-    char* s_a = smem + St::kBBytes;   // [patch pixel][CH ic]
+    constexpr int kBRegion = kDgrad ? St::kTBBytes : St::kBBytes;
+    char* s_b = smem;                 // [64 oc * 9 taps][CH ic]  (kDgrad: [9][CH][64])
+    char* s_a = smem + kBRegion;      // [patch pixel][CH ic]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pw = wave % PXW, kw = wave / PXW;
     const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
@@ -144,9 +154,17 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     int chunk_off = 0;  // c * CH of the chunk being fetched
 #define NF_LOAD_B(i)                                                                      \
     if constexpr (i < St::kBPerThread) {                                                  \
-        const int q = tid + i * 256, row = q >> kLog, p = q & (kPieces - 1);              \
-        pb##i = *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * g.Cin +   \
-                                                chunk_off + p * 8);                       \
+        if constexpr (kDgrad) {                                                           \
+            const int q = tid + i * 256, row = q >> 3, p = q & 7;                         \
+            const int tap = row / CH, kk = row - tap * CH;                                \
+            pb##i = *reinterpret_cast<const uint4*>(                                      \
+                w + (static_cast<long>(chunk_off + kk) * 9 + (8 - tap)) * g.Cout + oc0 +  \
+                p * 8);                                                                   \
+        } else {                                                                          \
+            const int q = tid + i * 256, row = q >> kLog, p = q & (kPieces - 1);          \
+            pb##i = *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * g.Cin + \
+                                                    chunk_off + p * 8);                   \
+        }                                                                                 \
     }
 #define NF_LOAD_A(i)                                                                      \
     {                                                                                     \
@@ -155,8 +173,13 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     }
 #define NF_STORE_B(i)                                                                     \
     if constexpr (i < St::kBPerThread) {                                                  \
-        const int q = tid + i * 256, row = q >> kLog, p = q & (kPieces - 1);              \
-        *reinterpret_cast<uint4*>(s_b + row * kPitch + p * 16) = pb##i;                   \
+        if constexpr (kDgrad) {                                                           \
+            const int q = tid + i * 256, row = q >> 3, p = q & 7;                         \
+            *reinterpret_cast<uint4*>(s_b + row * St::kTPitch + p * 16) = pb##i;          \
+        } else {                                                                          \
+            const int q = tid + i * 256, row = q >> kLog, p = q & (kPieces - 1);          \
+            *reinterpret_cast<uint4*>(s_b + row * kPitch + p * 16) = pb##i;               \
+        }                                                                                 \
     }
 #define NF_STORE_A(i) \
     if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(s_a + a_dst[i]) = pa##i;
@@ -188,8 +211,15 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
             const int boff = tap * kPitch + sub * 32;
             const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(s_a + a_row[0] + aoff);
             const bf16x8 A1 = *reinterpret_cast<const bf16x8*>(s_a + a_row[1] + aoff);
-            const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(s_b + b_row[0] + boff);
-            const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(s_b + b_row[1] + boff);
+            bf16x8 B0, B1;
+            if constexpr (kDgrad) {
+                const char* bt = s_b + tap * (CH * St::kTPitch);
+                B0 = load_tr_frag(bt, St::kTPitch, sub * 16, 0, lane);
+                B1 = load_tr_frag(bt, St::kTPitch, sub * 16, 32, lane);
+            } else {
+                B0 = *reinterpret_cast<const bf16x8*>(s_b + b_row[0] + boff);
+                B1 = *reinterpret_cast<const bf16x8*>(s_b + b_row[1] + boff);
+            }
             acc[0][0] = mfma32(A0, B0, acc[0][0]);
             acc[0][1] = mfma32(A0, B1, acc[0][1]);
             acc[1][0] = mfma32(A1, B0, acc[1][0]);
@@ -500,6 +530,41 @@ int wgrad_iterations(long M, int Cin, int Cout) {
     return static_cast<int>(nit);
 }
 
+template <bool kDgrad>
+int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int H, int W,
+               int Cin, int Cout, hipStream_t s) {
+    const int tp = fwd_tile_pixels(B, H, W, Cout);
+    ConvGeo g;
+    if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
+    if (!al16(x) || !al16(w) || !al16(y)) return -2;
+    const long M = static_cast<long>(B) * H * W;
+    const dim3 grid(static_cast<unsigned>(M / tp), Cout / 64);
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* wp = static_cast<const bf16*>(w);
+    bf16* yp = static_cast<bf16*>(y);
+    constexpr int kLdsCap = 124 * 1024;
+    static const int lds_ok =
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32, kDgrad>), kLdsCap) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64, kDgrad>), kLdsCap);
+    if (lds_ok != 0) return -20;
+    if (tp == 128) {
+        using St = FwdStage<32>;
+        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.np * St::kPitch;
+        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
+        if (lds > kLdsCap) return -20;
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32, kDgrad>), grid, dim3(256), lds, s, xp, wp,
+                           yp, colsum, g);
+    } else {
+        using St = FwdStage<64>;
+        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.np * St::kPitch;
+        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
+        if (lds > kLdsCap) return -20;
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64, kDgrad>), grid, dim3(256), lds, s, xp, wp,
+                           yp, colsum, g);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -523,36 +588,15 @@ int nf_conv3x3_fwd_tiles(int B, int H, int W, int Cout) {
 // tile's pixels for every channel (what a following BatchNorm needs).
 int nf_conv3x3_fwd(const void* x, const void* w, void* y, float* colsum, int B, int H, int W,
                    int Cin, int Cout, hipStream_t s) {
-    const int tp = fwd_tile_pixels(B, H, W, Cout);
-    ConvGeo g;
-    if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
-    if (!al16(x) || !al16(w) || !al16(y)) return -2;
-    const long M = static_cast<long>(B) * H * W;
-    const dim3 grid(static_cast<unsigned>(M / tp), Cout / 64);
-    const bf16* xp = static_cast<const bf16*>(x);
-    const bf16* wp = static_cast<const bf16*>(w);
-    bf16* yp = static_cast<bf16*>(y);
-    constexpr int kLdsCap = 112 * 1024;
-    static const int lds_ok =
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32>), kLdsCap) |
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64>), kLdsCap);
-    if (lds_ok != 0) return -20;
-    if (tp == 128) {
-        using St = FwdStage<32>;
-        int lds = St::kBBytes + g.np * St::kPitch;
-        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
-        if (lds > kLdsCap) return -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32>), grid, dim3(256), lds, s, xp, wp, yp, colsum,
-                           g);
-    } else {
-        using St = FwdStage<64>;
-        int lds = St::kBBytes + g.np * St::kPitch;
-        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
-        if (lds > kLdsCap) return -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64>), grid, dim3(256), lds, s, xp, wp, yp, colsum,
-                           g);
-    }
-    return static_cast<int>(hipGetLastError());
+    return launch_fwd<false>(x, w, y, colsum, B, H, W, Cin, Cout, s);
+}
+
+// dx[B][H][W][Cin] = data gradient of that convolution: dy[B][H][W][Cout] against the
+// same, unmodified w[Cout][3][3][Cin].
+int nf_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin,
+                     int Cout, hipStream_t s) {
+    // as a forward launch: reduction over the layer's Cout, output channels = its Cin
+    return launch_fwd<true>(dy, w, dx, nullptr, B, H, W, Cout, Cin, s);
 }
 
 // wt[Cin][3][3][Cout] = w[Cout][3][3][Cin] with reversed taps.

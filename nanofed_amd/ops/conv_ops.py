@@ -26,6 +26,7 @@ _SIGS = {
     "nf_conv3x3_supported": ([I, I, I, I, I], I),
     "nf_conv3x3_fwd": ([P, P, P, P, I, I, I, I, I, P], I),
     "nf_conv3x3_fwd_tiles": ([I, I, I, I], I),
+    "nf_conv3x3_dgrad": ([P, P, P, I, I, I, I, I, P], I),
     "nf_conv3x3_flip_weights": ([P, P, I, I, P], I),
     "nf_conv3x3_wgrad_workspace": ([I, I, I, I, I], L),
     "nf_conv3x3_wgrad": ([P, P, P, P, I, I, I, I, I, P], I),
@@ -96,13 +97,31 @@ def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, with_sums: bool = False):
 
 
 def conv3x3_input_grad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Gradient with respect to the input: dy [B, Cout, H, W] against the forward
+    weight w [Cout, Cin, 3, 3] as it is (the kernel reads it transposed, with the taps
+    reversed)."""
+    b, c_out, h, wd = dy.shape
+    c_in = w.shape[1]
+    dx = torch.empty((b, c_in, h, wd), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
+    library.check(
+        _fn("nf_conv3x3_dgrad")(_p(dy), _p(w), _p(dx), b, h, wd, c_in, c_out,
+                                library.stream_ptr(dy.device)),
+        "conv3x3_dgrad",
+    )
+    return dx
+
+
+def flipped_weights(w: torch.Tensor) -> torch.Tensor:
+    """[Cin, Cout, 3, 3] weights with reversed taps: ``conv3x3_forward(dy, flipped)`` is the
+    input gradient too (the path ``conv3x3_input_grad`` took before it read ``w``
+    directly; kept as a cross-check of the two kernels)."""
     c_out, c_in = w.shape[0], w.shape[1]
     wt = torch.empty((c_in, c_out, 3, 3), dtype=torch.bfloat16, device=w.device, memory_format=CL)
     library.check(
         _fn("nf_conv3x3_flip_weights")(_p(w), _p(wt), c_in, c_out, library.stream_ptr(w.device)),
         "conv3x3_flip_weights",
     )
-    return conv3x3_forward(dy, wt)
+    return wt
 
 
 def conv3x3_weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:

@@ -56,6 +56,9 @@ def test_forward_and_gradients(ops, shape):
     assert _rel(y, yr) < 6e-3  # bf16 rounding of the output
     dx = ops.conv3x3_input_grad(dy, wt)
     assert _rel(dx, xr.grad) < 6e-3
+    # the same gradient through the forward kernel on an explicitly flipped weight copy
+    dx2 = ops.conv3x3_forward(dy, ops.flipped_weights(wt))
+    assert _rel(dx2, xr.grad) < 6e-3
     dw = ops.conv3x3_weight_grad(x, dy)
     assert dw.shape == wr.grad.shape
     assert _rel(dw, wr.grad) < 6e-3
