@@ -1,0 +1,48 @@
+"""HIP streams for concurrent kernel chains.
+
+PyTorch hands out streams from a pool that it creates in one go, alternating
+between its priority levels; the HIP runtime deals hardware queues
+(``GPU_MAX_HW_QUEUES``, 4 per process by default) to streams round-robin in
+creation order, so consecutive pool streams of one priority can end up sharing
+hardware queues - their work then runs one chain after the other although it sits
+on different streams.  ``make_streams(n)`` creates ``n`` default-priority streams
+back to back with the runtime itself, which spreads them over the hardware queues,
+and wraps them for PyTorch.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+_HIP_STREAM_NON_BLOCKING = 0x01
+_keep_alive: list[int] = []
+
+
+def _runtime() -> ctypes.CDLL:
+    return ctypes.CDLL("libamdhip64.so")
+
+
+def make_streams(n: int, device: torch.device | int | None = None) -> list[torch.cuda.Stream]:
+    """``n`` new default-priority streams on ``device``, created consecutively."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else (
+        torch.device(device) if not isinstance(device, int) else torch.device("cuda", device))
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    out: list[torch.cuda.Stream] = []
+    try:
+        hip = _runtime()
+        create = hip.hipStreamCreateWithFlags
+        create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        create.restype = ctypes.c_int
+    except (OSError, AttributeError):
+        return [torch.cuda.Stream(dev) for _ in range(n)]
+    with torch.cuda.device(index):
+        for _ in range(n):
+            handle = ctypes.c_void_p()
+            if create(ctypes.byref(handle), _HIP_STREAM_NON_BLOCKING) != 0 or not handle.value:
+                out.append(torch.cuda.Stream(dev))
+                continue
+            _keep_alive.append(handle.value)  # lives as long as the process
+            out.append(torch.cuda.ExternalStream(handle.value, device=dev))
+    return out
