@@ -355,3 +355,45 @@ def test_idle_clients_are_skipped_without_changing_the_result():
     # the evaluation sums batches with float atomics: equal up to the summation order
     assert outs[0][2]["accuracy"] == outs[1][2]["accuracy"]
     assert outs[0][2]["loss"] == pytest.approx(outs[1][2]["loss"], rel=1e-5)
+
+
+def test_client_groups_train_the_same_model(monkeypatch):
+    """Four clients as two concurrent groups of two against one chain of four.  With
+    the kernel geometry pinned every client's partial sums are formed the same way,
+    so the models must agree bit for bit."""
+    from nanofed_amd.engine import EngineConfig, FederatedEngine
+    from nanofed_amd.parallel import Communicator
+
+    monkeypatch.setenv("NANOFED_MNIST_GEOMETRY", "1,32,1")
+    outs = []
+    for groups in (True, False):
+        torch.cuda.set_device(0)
+        cfg = EngineConfig(model="mnist_cnn", num_clients=4, samples_per_client=256, batch_size=64,
+                           local_epochs=3, eval_samples=64, backend="native", seed=4,
+                           client_streams=groups)
+        eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
+        assert len(eng.trainer._groups) == (2 if groups else 1)
+        reps = eng.run(2)   # six epochs: the stream trials and the chosen set
+        if groups:
+            assert len(eng.trainer._stream_trials) == eng.trainer.STREAM_TRIALS
+            assert eng.trainer._group_streams
+        outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reps]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+
+
+def test_make_streams_returns_usable_streams():
+    from nanofed_amd.utils.streams import make_streams
+
+    streams = make_streams(3, torch.device("cuda", 0))
+    assert len(streams) == 3 and len({s.cuda_stream for s in streams}) == 3
+    x = torch.ones(1024, device="cuda")
+    outs = []
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            outs.append(x * 2 + 1)
+    for s in streams:
+        torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert all(bool((o == 3).all()) for o in outs)
