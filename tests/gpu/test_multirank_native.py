@@ -35,6 +35,16 @@ comm.close()
 """
 
 
+def _free_port() -> int:
+    """A TCP port that is free right now (a fixed one can still be in TIME_WAIT from
+    the previous parametrisation)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 GEOMETRY = "1,32,1"  # the same kernel geometry whatever the number of clients per rank
 
 
@@ -45,7 +55,7 @@ def test_two_ranks_equal_one_rank(tmp_path, monkeypatch):
     script.write_text(WORKER.format(root=ROOT, cfg=CFG, out=str(out)))
     proc = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
         capture_output=True, text=True, timeout=280,
         env=dict(os.environ, MASTER_ADDR="127.0.0.1", NANOFED_MNIST_GEOMETRY=GEOMETRY),
     )
@@ -90,7 +100,7 @@ def test_rccl_collectives_single_rank_rehearsal(tmp_path, algo):
     out = tmp_path / f"rccl_{algo}.pt"
     script = tmp_path / "worker.py"
     script.write_text(RCCL_WORKER.format(root=ROOT, cfg=CFG, out=str(out), algo=algo))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0", NANOFED_FORCE_GROUP="1")
     proc = subprocess.run([sys.executable, str(script)], capture_output=True, text=True,
                           timeout=280, env=env)

@@ -100,6 +100,16 @@ def test_dp_batch_clip_path_runs_and_dirichlet_sharding():
     assert sum(c["metrics"]["samples_processed"] for c in rep.client_metrics) == 4 * 128
 
 
+def _free_port() -> int:
+    """A TCP port that is free right now (a fixed one can still be in TIME_WAIT from
+    the previous parametrisation)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 WORKER = r"""
 import sys, json, torch
 sys.path.insert(0, {root!r})
@@ -126,7 +136,7 @@ def test_two_process_gloo_run_matches_single_process(tmp_path, algo):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     proc = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
         capture_output=True, text=True, timeout=300, env=env,
     )
     assert proc.returncode == 0, proc.stderr[-2000:]
