@@ -298,6 +298,7 @@ class NativeBuffers:
 class MnistCnnNativeTrainer(GroupTrainer):
     make_layout = staticmethod(make_layout)
     STREAM_TRIALS = 4  # epochs spent choosing the group streams
+    HEAD_STEPS = 8     # steps in the short first graph of a group's epoch
 
     def __init__(
         self, cfg: EngineConfig, pool: ArenaPool, shards: DeviceShards, data: FederatedData
@@ -367,7 +368,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
                 self._groups.append(grp)
                 first += gs
             # (the streams are created at the first epoch, see _run_epoch)
-        self._graphs: list[torch.cuda.CUDAGraph] | None = None
+        self._graphs: list[list[torch.cuda.CUDAGraph]] | None = None
+        self._chunks: list[tuple[int, int]] = []
         self._stream_trials: list[tuple[float, list[torch.cuda.Stream]]] = []
         # staging table and (default-priority) side stream for the epoch shuffles
         self._idx_stage = torch.empty_like(self.buf.idx)
@@ -434,14 +436,23 @@ class MnistCnnNativeTrainer(GroupTrainer):
         counter = self.buf.step_counter.clone()
         self.buf.pack()
         self._fill_indices(round_idx, 0)
+        # Several groups: the host needs about 0.3 ms to enqueue a 118-step graph, so
+        # the groups' epochs would start staggered by that much.  Each group's epoch
+        # is therefore two graphs, a short head and the rest, launched head-first
+        # across the groups (all chains are running while the long graphs go out).
+        head = self.HEAD_STEPS if len(self._groups) > 1 and self.max_steps > self.HEAD_STEPS else 0
+        self._chunks = [(0, head), (head, self.max_steps - head)] if head else [(0, self.max_steps)]
         graphs = []
         for grp in self._groups:
             grp.train_steps(0, self.max_steps)
             torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                grp.train_steps(0, self.max_steps)
-            graphs.append(graph)
+            per_chunk = []
+            for first, count in self._chunks:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    grp.train_steps(first, count)
+                per_chunk.append(graph)
+            graphs.append(per_chunk)
         self._graphs = graphs
         self.pool.data.copy_(saved)
         self.buf.step_counter.copy_(counter)
@@ -449,7 +460,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
     def _run_epoch(self) -> None:
         if len(self._groups) == 1:
             if self._graphs is not None:
-                self._graphs[0].replay()
+                for graph in self._graphs[0]:
+                    graph.replay()
             else:
                 self.buf.train_steps(0, self.max_steps)
             return
@@ -470,11 +482,14 @@ class MnistCnnNativeTrainer(GroupTrainer):
             t0.record(main)
         for st in streams:
             st.wait_stream(main)
-        for i, grp in enumerate(self._groups):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                if self._graphs is not None:
-                    self._graphs[i].replay()
-                else:
+        if self._graphs is not None:
+            for c in range(len(self._chunks)):
+                for i in range(len(self._groups)):
+                    with torch.cuda.stream(streams[i % len(streams)]):
+                        self._graphs[i][c].replay()
+        else:
+            for i, grp in enumerate(self._groups):
+                with torch.cuda.stream(streams[i % len(streams)]):
                     grp.train_steps(0, self.max_steps)
         for st in streams:
             main.wait_stream(st)
