@@ -1,11 +1,13 @@
 """Native (hand-written HIP) local trainer for the MNIST CNN.
 
 Implements the ``GroupTrainer`` interface on top of csrc/hip/mnist_cnn.hip:
-all G simulated clients of a GPU advance one SGD step per group of ten kernel
-launches, and one local epoch (all steps of all clients) is recorded once in a
-hipGraph and replayed - the index table, the valid-sample table and the
-dropout step counter live in device memory, so a replay trains on the next
-epoch's shuffled batches without any host involvement.
+the simulated clients of a GPU advance one SGD step per chain of eight or nine
+kernel launches, each kernel working on several clients at once (blockIdx.y),
+and one local epoch is recorded once in hipGraphs and replayed - the index
+table, the valid-sample table and the dropout step counter live in device
+memory, so a replay trains on the next epoch's shuffled batches without any
+host involvement.  With four or more clients on the GPU the clients are split
+into pairs whose chains run on concurrent streams (views of one set of buffers).
 
 Training semantics are the reference's (nanofed/trainer/base.py:134-198 with
 nanofed/models/mnist.py:16-28 and nanofed/trainer/torch.py:14): per batch
