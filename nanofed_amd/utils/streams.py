@@ -21,7 +21,17 @@ _keep_alive: list[int] = []
 
 
 def _runtime() -> ctypes.CDLL:
-    return ctypes.CDLL("libamdhip64.so")
+    """The HIP runtime instance PyTorch itself uses (opening the library by its path
+    in this process's mappings, so that no second copy can come in)."""
+    try:
+        with open("/proc/self/maps") as maps:
+            for line in maps:
+                path = line.split()[-1]
+                if "libamdhip64" in path:
+                    return ctypes.CDLL(path)
+    except OSError:
+        pass
+    raise OSError("the HIP runtime is not loaded")
 
 
 def make_streams(n: int, device: torch.device | int | None = None) -> list[torch.cuda.Stream]:
