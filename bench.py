@@ -3,9 +3,14 @@
 One "step" is one complete federated round: broadcast of the global model,
 ``local_epochs`` epochs of SGD (batch 64) on every client's 7,500-sample IID
 shard, screening, weighted FedAvg reduce (RCCL all-reduce across GPUs), new
-global model.  The 8 clients are spread over the N GPUs (8/N per GPU), so the
-total work is fixed as N grows (strong scaling).  Data is synthetic
-MNIST-shaped, weights are random-init.
+global model, and - as in the reference's round
+(nanofed/orchestration/coordinator.py:346-357,247-280) - a saved model version
+(``.pt`` + config JSON) and a round-metrics JSON, written by rank 0 into a
+scratch directory; the writes of the last round are flushed before the clock
+stops.  ``rounds_per_s_no_persistence`` is the same loop timed once more without
+the writes.  The 8 clients are spread over the N GPUs (8/N per GPU), so the total
+work is fixed as N grows (strong scaling).  Data is synthetic MNIST-shaped,
+weights are random-init.
 
 Reference number: 53.48 s per round = 0.0187 rounds/s (3 clients, CPU, logged
 in examples/mnist/tutorial.ipynb:523 of the reference).
@@ -20,7 +25,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import torch
@@ -54,6 +61,11 @@ def main() -> int:
     ap.add_argument("--model", default="mnist_cnn")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="run on CPU/gloo (plumbing check)")
+    ap.add_argument("--no-persist", action="store_true",
+                    help="leave the per-round model version / metrics files out of the timed rounds")
+    ap.add_argument("--eval-samples", type=int, default=10000)
+    ap.add_argument("--dump-model", default=None,
+                    help="rank 0 saves the final global model (flat fp32 tensor) to this file")
     args = ap.parse_args()
 
     from nanofed_amd.engine import EngineConfig, FederatedEngine
@@ -85,26 +97,39 @@ def main() -> int:
         dtype=args.dtype,
         backend=args.backend,
         graph_capture=not args.no_graph,
-        eval_samples=10000,
+        eval_samples=args.eval_samples,
     )
-    engine = FederatedEngine(cfg, comm=comm)
+    scratch = None
+    if not args.no_persist and comm.is_root:
+        scratch = tempfile.mkdtemp(prefix="nanofed_bench_")
+    engine = FederatedEngine(cfg, comm=comm, base_dir=scratch)
 
     def sync() -> None:
         if comm.device.type == "cuda":
             torch.cuda.synchronize(comm.device)
 
+    def timed(rounds: int) -> tuple[float, list]:
+        comm.barrier()
+        sync()
+        t0 = time.perf_counter()
+        reps = [engine.run_round(flush=False) for _ in range(rounds)]
+        engine.flush()  # the last rounds' files are on disk before the clock stops
+        sync()
+        comm.barrier()
+        sync()
+        return comm.max_over_ranks(time.perf_counter() - t0), reps
+
     for _ in range(args.warmup):
         engine.run_round()
-    comm.barrier()
-    sync()
-    t0 = time.perf_counter()
-    reports = [engine.run_round() for _ in range(args.steps)]
-    sync()
-    comm.barrier()
-    sync()
-    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
-
+    elapsed, reports = timed(args.steps)
     final = engine.evaluate()
+    dump = engine.global_arena.data.detach().cpu().clone() if args.dump_model else None
+
+    # the same loop without the per-round files (what the writer thread costs)
+    bare = None
+    if scratch is not None or (not args.no_persist and comm.world_size > 1):
+        engine.disable_persistence()
+        bare, _ = timed(min(args.steps, 10))
     if comm.is_root:
         rounds_per_s = args.steps / elapsed
         last = reports[-1] if reports else None
@@ -121,6 +146,9 @@ def main() -> int:
             "vs_baseline": rounds_per_s / BASELINE_ROUNDS_PER_S,
             "dtype": args.dtype,
             "data": "synthetic MNIST-shaped, IID shards, random-init weights",
+            "persistence": "off" if args.no_persist else
+            "model version (.pt + JSON) and metrics JSON per round, writer thread, flushed in the timed region",
+            "rounds_per_s_no_persistence": (min(args.steps, 10) / bare) if bare else None,
             "final_test_accuracy": final.get("accuracy"),
             "final_train_accuracy": last.agg_metrics["accuracy"] if last else None,
             "final_train_loss": last.agg_metrics["loss"] if last else None,
@@ -139,10 +167,15 @@ def main() -> int:
                 "parallelism": f"fed{args.clients}/gpu{comm.world_size}",
             },
         }
+        if dump is not None:
+            torch.save(dump, args.dump_model)
         _restore_stdout(real_stdout)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
+    engine.close()
     comm.close()
+    if scratch is not None:
+        shutil.rmtree(scratch, ignore_errors=True)
     return 0
 
 

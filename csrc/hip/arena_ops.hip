@@ -321,6 +321,210 @@ scale_accumulate_kernel(float* __restrict__ out, const float* __restrict__ in, l
     if (t < n) out[t] = fmaf(b, in[t], a * out[t]);
 }
 
+// ---------------------------------------------------------------------------
+// Screening of all G client rows of a pool in two launches.
+//   stage 1, grid (bx, G): block (x, g) reduces its slice of row g (optionally of
+//            row g - ref) to [sum of squares of finite values, non-finite count]
+//   stage 2, grid (G):     fixed-order sum of the bx partials of row g, then the
+//            verdict: records[g][col_sq] = sum of squares,
+//            records[g][col_valid] *= (no non-finite value) && (norm bound holds)
+constexpr int kScreenBlocks = 64;
+
+__global__ void __launch_bounds__(kThreads)
+screen_rows_stage1(const float* __restrict__ rows, long row_stride, long n,
+                   const float* __restrict__ ref, float* __restrict__ partial) {
+    const int g = blockIdx.y;
+    const float* x = rows + static_cast<long>(g) * row_stride;
+    float sq = 0.f, bad = 0.f;
+    const long n4 = n >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (ref != nullptr) {
+            const float4 r = reinterpret_cast<const float4*>(ref)[i];
+            v.x -= r.x; v.y -= r.y; v.z -= r.z; v.w -= r.w;
+        }
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = isfinite(e[j]);
+            sq += ok ? e[j] * e[j] : 0.f;
+            bad += ok ? 0.f : 1.f;
+        }
+    }
+    const long t = (n4 << 2) + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float e = ref != nullptr ? x[t] - ref[t] : x[t];
+        const bool ok = isfinite(e);
+        sq += ok ? e * e : 0.f;
+        bad += ok ? 0.f : 1.f;
+    }
+    block_sum2(sq, bad);
+    if (threadIdx.x == 0) {
+        float* p = partial + (static_cast<long>(g) * gridDim.x + blockIdx.x) * 2;
+        p[0] = sq;
+        p[1] = bad;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+screen_rows_stage2(const float* __restrict__ partial, int blocks, float* __restrict__ records,
+                   int rec_stride, int col_sq, int col_valid, float max_sq) {
+    const int g = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* p = partial + static_cast<long>(g) * blocks * 2;
+    float sq = 0.f, bad = 0.f;
+    for (int i = 0; i < blocks; ++i) { sq += p[2 * i]; bad += p[2 * i + 1]; }
+    float* rec = records + static_cast<long>(g) * rec_stride;
+    const bool valid = bad == 0.f && (max_sq <= 0.f || sq <= max_sq);
+    rec[col_sq] = sq;
+    rec[col_valid] = valid ? rec[col_valid] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// FedAvg weights from the gathered per-client records, one workgroup:
+//   1. optional anomaly screen: client k is dropped when the norm of its update
+//      is more than z_thr standard deviations (unbiased, of the OTHER valid
+//      clients) away from their mean and at least min_stats others exist
+//   2. weights[k] = valid_k n_k / sum(valid n)
+//   3. flags = [round succeeded, valid clients, total samples, anomalous clients]
+// K is small (clients of the whole job), sums are taken by thread 0 in index order.
+__global__ void __launch_bounds__(64)
+round_weights_kernel(float* __restrict__ records, int K, int M, int col_samples, int col_valid,
+                     int col_sq, float required, float z_thr, int min_stats,
+                     float* __restrict__ weights, float* __restrict__ flags) {
+    if (threadIdx.x != 0) return;
+    int anomalous = 0;
+    if (z_thr > 0.f) {
+        double S = 0.0, Q = 0.0;
+        int m = 0;
+        for (int k = 0; k < K; ++k) {
+            if (records[k * M + col_valid] > 0.f) {
+                const double x = sqrt(static_cast<double>(records[k * M + col_sq]));
+                S += x; Q += x * x; ++m;
+            }
+        }
+        const int others = m - 1;
+        if (others >= min_stats && others >= 2) {
+            for (int k = 0; k < K; ++k) {
+                if (!(records[k * M + col_valid] > 0.f)) continue;
+                const double x = sqrt(static_cast<double>(records[k * M + col_sq]));
+                const double mean = (S - x) / others;
+                double var = (Q - x * x - others * mean * mean) / (others - 1);
+                if (var < 0.0) var = 0.0;
+                const double z = fabs(x - mean) / (sqrt(var) + 1e-8);
+                if (z > z_thr) { weights[k] = -1.f; ++anomalous; }
+                else weights[k] = 0.f;
+            }
+            for (int k = 0; k < K; ++k)
+                if (records[k * M + col_valid] > 0.f && weights[k] < 0.f)
+                    records[k * M + col_valid] = 0.f;
+        }
+    }
+    float total = 0.f, nvalid = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float v = records[k * M + col_valid] > 0.f ? 1.f : 0.f;
+        total += v * records[k * M + col_samples];
+        nvalid += v;
+    }
+    const float inv = 1.0f / fmaxf(total, 1e-30f);
+    for (int k = 0; k < K; ++k) {
+        const float v = records[k * M + col_valid] > 0.f ? 1.f : 0.f;
+        weights[k] = v * records[k * M + col_samples] * inv;
+    }
+    flags[0] = (nvalid >= required && total > 0.f) ? 1.f : 0.f;
+    flags[1] = nvalid;
+    flags[2] = total;
+    flags[3] = static_cast<float>(anomalous);
+}
+
+// dst = src when flag[0] > 0 (quorum select: the old model survives a failed round)
+__global__ void __launch_bounds__(kThreads)
+select_copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                   const float* __restrict__ flag, long n) {
+    if (!(flag[0] > 0.f)) return;
+    const long n4 = n >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    const long t = (n4 << 2) + static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+
+// ---------------------------------------------------------------------------
+// Pairwise-mask secure aggregation on flat rows.
+//   mask:   row = prescale * row + sum_p sign[p] * scale * U(seed[p])   (one client,
+//           all its peers, one pass)
+//   repair: total -= the masks that did not cancel because exactly one client of
+//           a pair is present (present[] and the K x K seed table live in device
+//           memory, so no host decision is needed between reduce and repair)
+// The uniform draw of a pair is philox(seed, offset, block) in MODE_SYM_UNIFORM,
+// the same stream philox_fill produces.
+constexpr int kMaxPeers = 64;
+struct PeerTable {
+    unsigned long long seed[kMaxPeers];
+    float sign[kMaxPeers];
+};
+
+__global__ void __launch_bounds__(kThreads)
+pairwise_mask_kernel(float* __restrict__ row, long n, float prescale, PeerTable t, int peers,
+                     float scale, unsigned long long offset) {
+    const long n4 = (n + 3) >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long b = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; b < n4; b += stride) {
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < peers; ++p) {
+            float s[4];
+            nf::philox_samples(t.seed[p], offset, static_cast<unsigned long long>(b), 3, s);
+            const float a = t.sign[p] * scale;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaf(a, s[j], m[j]);
+        }
+        const long base = b << 2;
+        if (base + 3 < n) {
+            float4 v = reinterpret_cast<float4*>(row)[b];
+            v.x = fmaf(prescale, v.x, m[0]); v.y = fmaf(prescale, v.y, m[1]);
+            v.z = fmaf(prescale, v.z, m[2]); v.w = fmaf(prescale, v.w, m[3]);
+            reinterpret_cast<float4*>(row)[b] = v;
+        } else {
+            for (int j = 0; j < 4 && base + j < n; ++j)
+                row[base + j] = fmaf(prescale, row[base + j], m[j]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+pairwise_repair_kernel(float* __restrict__ total, long n, const float* __restrict__ present,
+                       const unsigned long long* __restrict__ seeds /* [K][K] */, int K,
+                       float scale, unsigned long long offset) {
+    const long n4 = (n + 3) >> 2;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long b = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; b < n4; b += stride) {
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < K; ++i) {
+            const bool pi = present[i] > 0.f;
+            for (int j = i + 1; j < K; ++j) {
+                const bool pj = present[j] > 0.f;
+                if (pi == pj) continue;  // both masks arrived (they cancel) or neither did
+                // the survivor applied +scale when it is the smaller id, -scale otherwise
+                const float a = pi ? scale : -scale;
+                float s[4];
+                nf::philox_samples(seeds[i * K + j], offset, static_cast<unsigned long long>(b), 3, s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaf(a, s[e], m[e]);
+            }
+        }
+        const long base = b << 2;
+        if (base + 3 < n) {
+            float4 v = reinterpret_cast<float4*>(total)[b];
+            v.x -= m[0]; v.y -= m[1]; v.z -= m[2]; v.w -= m[3];
+            reinterpret_cast<float4*>(total)[b] = v;
+        } else {
+            for (int j = 0; j < 4 && base + j < n; ++j) total[base + j] -= m[j];
+        }
+    }
+}
+
 }  // namespace
 
 #define NF_CHECK_LAUNCH() (static_cast<int>(hipGetLastError()))
@@ -354,6 +558,68 @@ int nf_sqnorm_finite(const float* x, long n, float* workspace, float* result,
                        x, n, workspace);
     hipLaunchKernelGGL(sqnorm_finite_stage2, dim3(1), dim3(kThreads), 0, stream,
                        workspace, grid, result);
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_screen_workspace_floats(int rows) { return rows * kScreenBlocks * 2; }
+int nf_max_peers() { return kMaxPeers; }
+
+// rows: [G][row_stride] (n used elements each); ref: null or n floats subtracted
+// from every row first; workspace: nf_screen_workspace_floats(G) floats;
+// records: [G][rec_stride], columns col_sq / col_valid are written.
+int nf_screen_rows(const float* rows, int G, long row_stride, long n, const float* ref,
+                   float* workspace, float* records, int rec_stride, int col_sq, int col_valid,
+                   float max_sq, hipStream_t stream) {
+    if (G < 1 || n < 0 || row_stride < n || col_sq < 0 || col_valid < 0 ||
+        col_sq >= rec_stride || col_valid >= rec_stride)
+        return -1;
+    if ((row_stride & 3) != 0) return -2;  // every row must keep float4 alignment
+    int bx = grid_for((n + 3) >> 2);
+    if (bx > kScreenBlocks) bx = kScreenBlocks;
+    hipLaunchKernelGGL(screen_rows_stage1, dim3(bx, G), dim3(kThreads), 0, stream, rows,
+                       row_stride, n, ref, workspace);
+    hipLaunchKernelGGL(screen_rows_stage2, dim3(G), dim3(64), 0, stream, workspace, bx, records,
+                       rec_stride, col_sq, col_valid, max_sq);
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_round_weights(float* records, int K, int M, int col_samples, int col_valid, int col_sq,
+                     float required, float z_thr, int min_stats, float* weights, float* flags,
+                     hipStream_t stream) {
+    if (K < 1 || M < 1 || col_samples >= M || col_valid >= M || col_sq >= M) return -1;
+    hipLaunchKernelGGL(round_weights_kernel, dim3(1), dim3(64), 0, stream, records, K, M,
+                       col_samples, col_valid, col_sq, required, z_thr, min_stats, weights, flags);
+    return NF_CHECK_LAUNCH();
+}
+
+int nf_select_copy(float* dst, const float* src, const float* flag, long n, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    hipLaunchKernelGGL(select_copy_kernel, dim3(grid_for((n + 3) >> 2)), dim3(kThreads), 0, stream,
+                       dst, src, flag, n);
+    return NF_CHECK_LAUNCH();
+}
+
+// seeds / signs: host arrays of `peers` entries (<= nf_max_peers() per call).
+int nf_pairwise_mask(float* row, long n, float prescale, const unsigned long long* seeds,
+                     const float* signs, int peers, float scale, unsigned long long offset,
+                     hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    if (peers < 0 || peers > kMaxPeers) return -1;
+    PeerTable t = {};
+    for (int p = 0; p < peers; ++p) { t.seed[p] = seeds[p]; t.sign[p] = signs[p]; }
+    hipLaunchKernelGGL(pairwise_mask_kernel, dim3(grid_for((n + 3) >> 2)), dim3(kThreads), 0,
+                       stream, row, n, prescale, t, peers, scale, offset);
+    return NF_CHECK_LAUNCH();
+}
+
+// present: device, K floats; seeds: device, K*K uint64 (entry [i][j], i < j, is used).
+int nf_pairwise_repair(float* total, long n, const float* present,
+                       const unsigned long long* seeds, int K, float scale,
+                       unsigned long long offset, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : -1;
+    if (K < 2) return -1;
+    hipLaunchKernelGGL(pairwise_repair_kernel, dim3(grid_for((n + 3) >> 2)), dim3(kThreads), 0,
+                       stream, total, n, present, seeds, K, scale, offset);
     return NF_CHECK_LAUNCH();
 }
 

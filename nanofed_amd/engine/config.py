@@ -70,13 +70,40 @@ class EngineConfig:
     min_completion_rate: float = 1.0
     validate_updates: bool = True
     max_update_norm: float = 0.0  # 0 disables the norm bound (finite check stays)
+    # anomaly screen on the update norms ||theta_k - theta|| (reference:
+    # ValidationConfig.z_score_threshold / min_clients_for_stats,
+    # nanofed/server/validation.py:25-33,103-135): a client further than this many
+    # standard deviations from the mean of the OTHER valid clients is left out;
+    # 0 disables the screen
+    zscore_threshold: float = 0.0
+    min_clients_for_stats: int = 5
+    # secure aggregation on the device plane: "pairwise" blinds every client row
+    # with seeded pairwise masks that cancel in the reduce (dropped clients'
+    # unmatched masks are removed on device); "none" reduces the plain rows
+    secure_agg: str = "none"
+    secure_mask_scale: float = 1.0
     # a client that reports later than this many seconds is left out of the round
     # (reference: CoordinatorConfig.round_timeout); 0 = wait for everybody
     round_timeout_s: float = 0.0
+    # True: a watchdog thread enforces round_timeout_s on the wall clock - a round
+    # that overruns it (a stalled rank blocks every collective) is recorded as
+    # FAILED and the process ends with exit code WATCHDOG_EXIT_CODE, so that a
+    # supervisor can start a fresh process that resume()s (reference: TimeoutError
+    # + RoundStatus.FAILED, nanofed/orchestration/coordinator.py:205-245,295-304).
+    # The first round of a process gets first_round_grace_s on top (graph capture,
+    # library warm-up).
+    enforce_round_timeout: bool = False
+    first_round_grace_s: float = 120.0
     # fault tolerance: write a FileStateStore checkpoint after every completed
     # round and roll back to the last one on a recoverable failure
     checkpoint_rounds: bool = False
     max_recoveries: int = 2
+    # persistence (model version, metrics JSON, checkpoint) runs on a writer thread
+    # fed by a device->pinned-host copy on a side stream; False writes inline
+    async_persist: bool = True
+    # capture the round's tail (screening, weights, weighted sum, select) in a
+    # hipGraph (single-rank GPU runs)
+    tail_graph: bool = True
     # observability: HIP-event timing of the round's phases (extra key
     # "phases_ms" in the round metrics JSON)
     phase_timing: bool = True

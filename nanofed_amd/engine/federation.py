@@ -12,17 +12,22 @@ simulated clients in one arena pool and the round is
 
     1. expand-copy of the global arena into the pool          (broadcast)
     2. ``GroupTrainer.train_round``                            (local training)
-    3. per-client finite / norm screening on the device        (validation -> mask)
-    4. all-gather of a 6-float record per client               (metrics, counts)
-    5. weights = mask * n / sum(mask * n), computed on device
+    3. screening of all client rows in two launches            (validation -> mask)
+    4. all-gather of a 6-float record per client + one control row per rank
+    5. anomaly screen, weights = mask * n / sum(mask * n), quorum flag: one launch
     6. fused weighted sum over the local rows, then one all-reduce (FedAvg)
     7. quorum select: keep the old model if too few valid updates
     8. ONE device->host copy of the gathered records           (round report)
+    9. persistence on a writer thread (device->pinned copy on a side stream)
 
-Steps 1-7 issue no host synchronisation.  Dropped, straggling or poisoned
-clients are expressed as a zero in the participation mask, because a
-collective cannot time out per peer (the reference polls for a quorum of
-HTTP submissions instead, coordinator.py:205-245).
+Steps 1-7 issue no host synchronisation; on a single-rank GPU run steps 3-7 are
+one hipGraph replay.  Dropped, straggling, anomalous or poisoned clients are
+expressed as a zero in the participation mask, because a collective cannot time
+out per peer (the reference polls for a quorum of HTTP submissions instead,
+coordinator.py:205-245).  A rank whose local training raised still enters every
+collective of the round (with an all-invalid record block) and reports the
+failure in its control row, so all ranks learn about it at step 8 and take the
+recovery decision together.
 
 Persistence keeps the reference's formats: ``ModelManager`` versions
 (``models/models/*.pt`` + ``models/configs/*.json``) and
@@ -31,7 +36,11 @@ Persistence keeps the reference's formats: ``ModelManager`` versions
 
 from __future__ import annotations
 
+import hashlib
 import json
+import os
+import queue
+import threading
 import time
 from dataclasses import asdict, dataclass, field
 from pathlib import Path
@@ -62,6 +71,21 @@ from .trainers import (
     TorchGroupTrainer,
 )
 
+# exit status of a process whose watchdog saw a round overrun its time limit
+# (EX_TEMPFAIL: a supervisor may start a fresh process that resumes)
+WATCHDOG_EXIT_CODE = 75
+
+
+class RoundFailure(RuntimeError):
+    """A round failed on at least one rank; raised on EVERY rank after the
+    round's collectives, so that recovery starts from a common point.
+    ``local`` is this rank's own exception (None when only a peer failed)."""
+
+    def __init__(self, message: str, local: BaseException | None, failed_ranks: list[int]) -> None:
+        super().__init__(message)
+        self.local = local
+        self.failed_ranks = failed_ranks
+
 
 @dataclass
 class RoundReport:
@@ -80,20 +104,121 @@ class RoundReport:
 class FaultPlan:
     """Fault injection for tests and drills: ``drop[r]`` = client ids that
     submit nothing in round r; ``poison[r]`` = client ids whose update is
-    overwritten with NaNs before screening; ``delay[r]`` = {client id: seconds
-    the client reports late} (left out when later than ``round_timeout_s``);
-    ``fail[r]`` = message of a ``RuntimeError`` raised once in the middle of
-    round r, the way a HIP or RCCL error would surface."""
+    overwritten with NaNs before screening; ``scale[r]`` = {client id: factor
+    its update (theta_k - theta) is multiplied by} (a model-poisoning client);
+    ``delay[r]`` = {client id: seconds the client reports late} (left out when
+    later than ``round_timeout_s``); ``fail[r]`` = message of a ``RuntimeError``
+    raised once in the middle of round r, the way a HIP or RCCL error would
+    surface, on every rank - or only on the ranks in ``fail_ranks`` when that is
+    set; ``stall[r]`` = {rank: seconds that rank sleeps inside round r} (a hung
+    peer, for watchdog drills)."""
 
     drop: dict[int, set[int]] = field(default_factory=dict)
     poison: dict[int, set[int]] = field(default_factory=dict)
+    scale: dict[int, dict[int, float]] = field(default_factory=dict)
     delay: dict[int, dict[int, float]] = field(default_factory=dict)
     fail: dict[int, str] = field(default_factory=dict)
+    fail_ranks: set[int] | None = None
+    stall: dict[int, dict[int, float]] = field(default_factory=dict)
 
 
 def clients_of_rank(num_clients: int, world: int, rank: int) -> list[int]:
     """Contiguous block placement of clients on ranks (sizes differ by <= 1)."""
     return [int(c) for c in np.array_split(np.arange(num_clients), world)[rank]]
+
+
+class _Watchdog:
+    """Wall-clock limit on a round.  ``arm`` before a round, ``disarm`` after; if
+    a round is still armed past its deadline the monitor thread writes a FAILED
+    marker (rank 0, when a directory is known) and ends the process - a rank that
+    is blocked inside a collective cannot be unblocked from the host, and a
+    process that has used the GPU must not be re-executed in place, so recovery is
+    a fresh process that calls ``resume()``."""
+
+    def __init__(self, limit_s: float, first_grace_s: float, on_timeout: Callable[[int, float], None]) -> None:
+        self.limit_s = limit_s
+        self.first_grace_s = first_grace_s
+        self._on_timeout = on_timeout
+        self._lock = threading.Lock()
+        self._deadline: float | None = None
+        self._round = -1
+        self._rounds_seen = 0
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._watch, name="nanofed-watchdog", daemon=True)
+        self._thread.start()
+
+    def arm(self, round_id: int) -> None:
+        with self._lock:
+            extra = self.first_grace_s if self._rounds_seen == 0 else 0.0
+            self._deadline = time.monotonic() + self.limit_s + extra
+            self._round = round_id
+            self._rounds_seen += 1
+
+    def disarm(self) -> None:
+        with self._lock:
+            self._deadline = None
+
+    def close(self) -> None:
+        self._stop.set()
+
+    def _watch(self) -> None:
+        while not self._stop.wait(0.05):
+            with self._lock:
+                deadline, rnd = self._deadline, self._round
+            if deadline is not None and time.monotonic() > deadline:
+                self._on_timeout(rnd, self.limit_s)
+                return
+
+
+class _Persister:
+    """Writer thread for the per-round persistence.  The main thread enqueues a
+    job (host snapshot of the global arena + the report); the thread turns it into
+    a model version, a metrics file and, when enabled, a checkpoint.  The queue is
+    bounded by the number of snapshot buffers, so a slow disk slows the rounds
+    down instead of growing memory.  An exception in the thread is kept and raised
+    on the main thread at the next ``submit`` / ``flush``."""
+
+    def __init__(self, write: Callable[[dict], None], slots: int = 2) -> None:
+        self._write = write
+        self._jobs: queue.Queue = queue.Queue(maxsize=slots)
+        self._error: BaseException | None = None
+        self.write_s = 0.0
+        self.jobs_done = 0
+        self._thread = threading.Thread(target=self._loop, name="nanofed-persist", daemon=True)
+        self._thread.start()
+
+    def _loop(self) -> None:
+        while True:
+            job = self._jobs.get()
+            try:
+                if job is None:
+                    return
+                if self._error is None:
+                    t0 = time.perf_counter()
+                    self._write(job)
+                    self.write_s += time.perf_counter() - t0
+                    self.jobs_done += 1
+            except BaseException as exc:  # noqa: BLE001 - re-raised on the main thread
+                self._error = exc
+            finally:
+                self._jobs.task_done()
+
+    def raise_pending(self) -> None:
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def submit(self, job: dict) -> None:
+        self.raise_pending()
+        self._jobs.put(job)
+
+    def flush(self) -> None:
+        self._jobs.join()
+        self.raise_pending()
+
+    def close(self) -> None:
+        self._jobs.join()
+        self._jobs.put(None)
 
 
 class FederatedEngine:
@@ -114,6 +239,8 @@ class FederatedEngine:
         self.base_dir = Path(base_dir) if base_dir is not None else None
         self.round_id = 0
         self.reports: list[RoundReport] = []
+        if cfg.secure_agg not in ("none", "pairwise"):
+            raise DeviceError(f"unknown secure_agg mode {cfg.secure_agg!r}")
 
         if cfg.num_clients < self.comm.world_size:
             raise DeviceError(
@@ -128,6 +255,7 @@ class FederatedEngine:
         ]
         self.max_local = max(counts)
         self._rank_counts = counts
+        self._even = len(set(counts)) == 1
 
         torch.manual_seed(cfg.seed)  # identical initial model on every rank
         self._model_factory = lambda: build_model(cfg.model, **cfg.model_kwargs)
@@ -155,20 +283,50 @@ class FederatedEngine:
         self.pool = ArenaPool(self.layout, len(self.client_ids), self.device)
         self.trainer = self._make_trainer(trainer_factory)
 
-        K = cfg.num_clients
-        self._partial = torch.zeros(self.layout.numel, dtype=torch.float32, device=self.device)
-        self._local_records = torch.zeros(
-            self.max_local, METRIC_COLUMNS, dtype=torch.float32, device=self.device
-        )
-        self._screen = torch.zeros(len(self.client_ids), 2, dtype=torch.float32, device=self.device)
-        self._delta = torch.zeros(self.layout.numel, dtype=torch.float32, device=self.device)
+        K, G, W = cfg.num_clients, len(self.client_ids), self.comm.world_size
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self._K = K
+        self._partial = torch.zeros(self.layout.numel, **f32)
+        # per-client records of this rank + one control row [failed flag, ...]
+        self._local_records = torch.zeros(self.max_local + 1, METRIC_COLUMNS, **f32)
+        self._records = torch.zeros(K, METRIC_COLUMNS, **f32)
+        self._weights = torch.zeros(K, **f32)
+        self._flags = torch.zeros(4, **f32)
+        self._control = torch.zeros(W, **f32)
+        # everything the host reads at the end of a round, in one buffer
+        self._host_pack = torch.zeros(K * METRIC_COLUMNS + 4 + W, **f32)
+        self._need_delta = cfg.max_update_norm > 0 or cfg.zscore_threshold > 0
+        self._tail_graph: torch.cuda.CUDAGraph | None = None
+        self._tail_rounds = 0
+        self._secure_seeds: torch.Tensor | None = None
+        self._shares: torch.Tensor | None = None
+        if cfg.secure_agg == "pairwise":
+            self._setup_secure_agg()
+
         self._model_manager = None
         self._recovery = None
         self.recoveries = 0
+        self._resumed = False
+        self._stale_checked = False
         self._timer = PhaseTimer(self.device)
+        self._persister: _Persister | None = None
+        self._snap_slots: list[torch.Tensor] = []
+        self._snap_events: list = []
+        self._snap_next = 0
+        self._copy_stream = None
+        # recovery point of last resort (no completed checkpoint yet): the global
+        # model as it was when the failed round began
+        self._round_start = (
+            torch.empty_like(self.global_arena.data) if cfg.checkpoint_rounds else None
+        )
         if self.base_dir is not None and self.comm.is_root:
             self._setup_persistence()
-        self._K = K
+        self._in_run = False
+        self._watchdog: _Watchdog | None = None
+        if cfg.enforce_round_timeout and cfg.round_timeout_s > 0:
+            self._watchdog = _Watchdog(
+                cfg.round_timeout_s, cfg.first_round_grace_s, self._on_round_timeout
+            )
 
     # -- construction helpers ---------------------------------------------
     def _make_trainer(self, factory: Callable[..., GroupTrainer] | None) -> GroupTrainer:
@@ -195,10 +353,11 @@ class FederatedEngine:
         if cfg.backend != "auto":
             return cfg.backend
         on_gpu = self.device.type == "cuda"
-        mnist_ok = (
-            cfg.model == "mnist_cnn" and on_gpu
-            and (cfg.dp is None or cfg.dp.mode == "per_sample") and cfg.batch_size == 64
-        )
+        mnist_ok = False
+        if cfg.model == "mnist_cnn" and on_gpu:
+            from .mnist_native import supports
+
+            mnist_ok = supports(cfg)
         gpt2_ok = False
         if cfg.model.startswith("gpt2") and on_gpu and cfg.dp is None and cfg.dtype == "bf16":
             m = self._host_model.cfg
@@ -220,70 +379,124 @@ class FederatedEngine:
             from nanofed_amd.server.fault_tolerance import FaultTolerantCoordinator
 
             self._recovery = FaultTolerantCoordinator(base)
+        n_slots = 2
+        pin = self.device.type == "cuda"
+        self._snap_slots = [
+            torch.empty(self.layout.numel, dtype=torch.float32, pin_memory=pin)
+            for _ in range(n_slots)
+        ]
+        if pin:
+            self._copy_stream = torch.cuda.Stream(self.device)
+            self._snap_events = [torch.cuda.Event() for _ in range(n_slots)]
+        if self.cfg.async_persist:
+            self._persister = _Persister(self._write_job, slots=n_slots - 1)
+
+    def enable_persistence(self, base_dir: str | Path) -> None:
+        """Start writing model versions / metrics / checkpoints under
+        ``base_dir`` from the next round on (rank 0 only writes)."""
+        self.flush()
+        self.base_dir = Path(base_dir)
+        if self.comm.is_root:
+            self._setup_persistence()
+
+    def disable_persistence(self) -> None:
+        """Stop writing per-round files (the files written so far stay)."""
+        self.flush()
+        if self._persister is not None:
+            self._persister.close()
+            self._persister = None
+        self._model_manager = None
+        self._recovery = None
+
+    def _setup_secure_agg(self) -> None:
+        """Pair seeds of the blinding masks.  Stand-in for pairwise key agreement:
+        derived from the run seed so that every rank (and a test) computes the same
+        table; entry [i][j] = [j][i]."""
+        K = self.cfg.num_clients
+        if K < 2:
+            raise DeviceError("pairwise secure aggregation needs at least two clients")
+        table = torch.zeros(K, K, dtype=torch.int64)
+        for i in range(K):
+            for j in range(i + 1, K):
+                digest = hashlib.sha256(f"nanofed|{self.cfg.seed}|{i}|{j}".encode()).digest()
+                table[i, j] = table[j, i] = int.from_bytes(digest[:8], "big") >> 1
+        self._secure_seed_table = table
+        self._secure_seeds = table.to(self.device)
+        # a client's share of the total sample count is public metadata (the
+        # counts travel in the clear in the reference too, client.py:180-189)
+        sizes = torch.tensor([float(len(s)) for s in self.data.shards], dtype=torch.float32)
+        self._shares_host = (sizes / sizes.sum().clamp(min=1.0)).tolist()
+        self._shares = torch.tensor(self._shares_host, dtype=torch.float32).to(self.device)
 
     # -- the round --------------------------------------------------------
-    def run_round(self) -> RoundReport:
-        cfg, comm = self.cfg, self.comm
+    def run_round(self, flush: bool | None = None) -> RoundReport:
+        """One federated round.  ``flush=False`` leaves the round's persistence
+        with the writer thread (``run`` and the benchmark flush once at the end);
+        the default flushes unless the call comes from ``run``."""
+        if flush is None:
+            flush = not self._in_run
         r = self.round_id
         t0 = time.perf_counter()
         start = get_current_time()
+        if self._watchdog is not None:
+            self._watchdog.arm(r)
+        try:
+            report = self._round(r, t0, start)
+        finally:
+            if self._watchdog is not None:
+                self._watchdog.disarm()
+        if flush:
+            self.flush()
+        return report
 
+    def _round(self, r: int, t0: float, start) -> RoundReport:
+        cfg, comm = self.cfg, self.comm
         timer = self._timer
+        multi = comm.world_size > 1
+        failure: BaseException | None = None
+        # a persistence error of an earlier round (rank 0) becomes this round's failure
+        if self._persister is not None:
+            try:
+                self._persister.raise_pending()
+            except Exception as exc:  # noqa: BLE001
+                failure = exc
         # 1. broadcast
         with timer.phase("broadcast"):
             self.pool.broadcast_from(self.global_arena.data)
+            if self._round_start is not None:
+                self._round_start.copy_(self.global_arena.data)
         # 2. local training
-        with timer.phase("local_train"):
-            local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
-        # fault injection
-        if r in self.faults.fail:
-            raise RuntimeError(self.faults.fail.pop(r))
-        late = {
-            cid for cid, secs in self.faults.delay.get(r, {}).items()
-            if cfg.round_timeout_s > 0 and secs > cfg.round_timeout_s
-        }
-        for k, cid in enumerate(self.client_ids):
-            if cid in self.faults.poison.get(r, ()):
-                self.pool[k].data.fill_(float("nan"))
-            if cid in self.faults.drop.get(r, ()) or cid in late:
-                local[k, M_VALID] = 0.0
-        with timer.phase("screen_gather"):
-            # 3. screening -> participation mask
-            if cfg.validate_updates:
-                self._screen_updates(local)
-            # 4. gather the per-client records
-            self._local_records.zero_()
-            self._local_records[: len(self.client_ids)].copy_(local)
-            gathered = comm.allgather(self._local_records)  # [W, max_local, M]
-            records = torch.cat(
-                [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
-            )  # [K, M] in client-id order
-        with timer.phase("reduce"):
-            # 5. weights on device
-            mask = records[:, M_VALID]
-            mass = mask * records[:, M_SAMPLES]
-            total = mass.sum()
-            weights = mass / total.clamp(min=1e-30)
-            n_valid = mask.sum()
-            ok = (n_valid >= float(cfg.required_clients())) & (total > 0)
-            lo = self.client_ids[0]
-            w_local = weights[lo : lo + len(self.client_ids)]
-            # 6. FedAvg: fused local weighted sum + one all-reduce (rows with
-            #    weight 0 are never read, so a poisoned row cannot leak NaNs)
-            ops.weighted_sum(self.pool.rows(), w_local, out=self._partial)
-            comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
-            # 7. quorum select (device-side; the old model survives a failed round)
-            self.global_arena.data.copy_(
-                torch.where(ok, self._partial, self.global_arena.data)
-            )
+        local = None
+        try:
+            if failure is None:
+                with timer.phase("local_train"):
+                    local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
+                self._inject_faults(r, local)
+        except Exception as exc:  # noqa: BLE001 - agreed on below, re-raised on every rank
+            failure = exc
+        if failure is not None and not multi:
+            raise failure
+        self._tail(local, failed=failure is not None, eager=failure is not None or self._faulty(r))
         # 8. the only host synchronisation of the round
-        host = torch.cat([records.reshape(-1), ok.float().reshape(1)]).cpu()
-        rec = host[:-1].view(-1, METRIC_COLUMNS).numpy()
-        succeeded = bool(host[-1] > 0)
+        host = self._host_pack.cpu()
+        K, W = self._K, comm.world_size
+        rec = host[: K * METRIC_COLUMNS].view(K, METRIC_COLUMNS).numpy()
+        flags = host[K * METRIC_COLUMNS : K * METRIC_COLUMNS + 4]
+        control = host[K * METRIC_COLUMNS + 4 :]
+        if bool((control > 0).any()):
+            ranks = [w for w in range(W) if control[w] > 0]
+            raise RoundFailure(
+                f"round {r} failed on rank(s) {ranks}"
+                + (f": {type(failure).__name__}: {failure}" if failure is not None else ""),
+                failure, ranks,
+            ) from failure
+        succeeded = bool(flags[0] > 0)
         phases = timer.collect() if cfg.phase_timing else {}
 
         report = self._report(r, rec, succeeded, start, time.perf_counter() - t0)
         report.phases_ms = phases
+        if flags[3] > 0:
+            report.agg_metrics["anomalous_clients"] = float(flags[3])
         self.reports.append(report)
         if succeeded:
             self.round_id += 1
@@ -293,23 +506,142 @@ class FederatedEngine:
                 report.phases_ms["checkpoint"] = (time.perf_counter() - t_ck) * 1000.0
         return report
 
-    def _screen_updates(self, local: torch.Tensor) -> None:
-        """Finite check (+ optional bound on ||theta_k - theta||) per client,
-        written into the participation column without leaving the device."""
+    def _faulty(self, r: int) -> bool:
+        f = self.faults
+        return any(r in d for d in (f.drop, f.poison, f.scale, f.delay, f.fail, f.stall))
+
+    def _inject_faults(self, r: int, local: torch.Tensor) -> None:
         cfg = self.cfg
-        for k in range(len(self.client_ids)):
-            row = self.pool[k].data
-            if cfg.max_update_norm > 0:
-                torch.sub(row, self.global_arena.data, out=self._delta)
-                ops.sqnorm_finite(self._delta, out=self._screen[k])
+        f = self.faults
+        if r in f.stall and self.comm.rank in f.stall[r]:
+            time.sleep(f.stall[r][self.comm.rank])
+        if r in f.fail and (f.fail_ranks is None or self.comm.rank in f.fail_ranks):
+            raise RuntimeError(f.fail.pop(r))
+        late = {
+            cid for cid, secs in f.delay.get(r, {}).items()
+            if cfg.round_timeout_s > 0 and secs > cfg.round_timeout_s
+        }
+        for k, cid in enumerate(self.client_ids):
+            if cid in f.scale.get(r, {}):
+                row = self.pool[k].data
+                g = self.global_arena.data
+                row.copy_(g + (row - g) * float(f.scale[r][cid]))
+            if cid in f.poison.get(r, ()):
+                self.pool[k].data.fill_(float("nan"))
+            if cid in f.drop.get(r, ()) or cid in late:
+                local[k, M_VALID] = 0.0
+
+    # steps 3-7
+    def _tail(self, local: torch.Tensor | None, failed: bool, eager: bool) -> None:
+        graphable = (
+            self.cfg.tail_graph and self.device.type == "cuda" and self.comm.world_size == 1
+            and not eager and local is not None
+        )
+        if graphable:
+            if self._tail_graph is None and self._tail_rounds >= 1:
+                # captured on the second eager-free round: every buffer exists and the
+                # trainer's metrics tensor has its final address
+                self._tail_local = local
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._tail_ops(local, failed=False)
+                self._tail_graph = graph
+            if self._tail_graph is not None and local.data_ptr() == self._tail_local.data_ptr():
+                with self._timer.phase("tail_graph"):
+                    self._tail_graph.replay()
+                self._tail_rounds += 1
+                return
+        self._tail_ops(local, failed, self._timer)
+        self._tail_rounds += 1
+
+    def _tail_ops(self, local: torch.Tensor | None, failed: bool, timer: PhaseTimer | None = None) -> None:
+        """Steps 3-7.  ``timer`` is None while the steps are being recorded into a
+        graph (events cannot be taken inside a capture)."""
+        from contextlib import nullcontext
+
+        cfg, comm = self.cfg, self.comm
+        G, K, M = len(self.client_ids), self._K, METRIC_COLUMNS
+        rec = self._local_records
+        with timer.phase("screen_gather") if timer is not None else nullcontext():
+            rec.zero_()
+            if local is not None and not failed:
+                rec[:G].copy_(local)
+                # 3. screening -> participation mask
+                if cfg.validate_updates:
+                    ops.screen_rows(
+                        self.pool.data, rec, M_UPDATE_SQNORM, M_VALID,
+                        ref=self.global_arena.data if self._need_delta else None,
+                        max_norm=cfg.max_update_norm,
+                    )
+            if failed:
+                rec[self.max_local, 0] = 1.0
+            # 4. gather the per-client records (+ control rows)
+            if comm.world_size == 1:
+                records = rec[:K]
+                self._control.copy_(rec[self.max_local, :1])
             else:
-                ops.sqnorm_finite(row, out=self._screen[k])
-        finite = self._screen[:, 1] == 0
-        valid = finite
-        if cfg.max_update_norm > 0:
-            valid = valid & (self._screen[:, 0] <= cfg.max_update_norm**2)
-        local[:, M_UPDATE_SQNORM] = self._screen[:, 0]
-        local[:, M_VALID] = local[:, M_VALID] * valid.float()
+                gathered = comm.allgather(rec)  # [W, max_local + 1, M]
+                if self._even:
+                    self._records.copy_(gathered[:, : self.max_local].reshape(K, M))
+                else:
+                    self._records.copy_(torch.cat(
+                        [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
+                    ))
+                records = self._records
+                self._control.copy_(gathered[:, self.max_local, 0])
+        with timer.phase("reduce") if timer is not None else nullcontext():
+            self._reduce_select(records, G, K, M)
+
+    def _reduce_select(self, records: torch.Tensor, G: int, K: int, M: int) -> None:
+        cfg, comm = self.cfg, self.comm
+        # 5. anomaly screen, weights, quorum flag: one launch
+        ops.round_weights(
+            records, M_SAMPLES, M_VALID, M_UPDATE_SQNORM, float(cfg.required_clients()),
+            self._weights, self._flags, z_threshold=cfg.zscore_threshold,
+            min_clients_for_stats=cfg.min_clients_for_stats,
+        )
+        lo = self.client_ids[0]
+        # 6. FedAvg: fused local weighted sum + one all-reduce (rows with weight 0
+        #    are never read, so a poisoned row cannot leak NaNs)
+        if cfg.secure_agg == "pairwise":
+            self._secure_reduce(records, lo, G)
+        else:
+            ops.weighted_sum(self.pool.rows(), self._weights[lo : lo + G], out=self._partial)
+            comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
+        # 7. quorum select (device-side; the old model survives a failed round)
+        ops.select_copy(self.global_arena.data, self._partial, self._flags)
+        pack = self._host_pack
+        pack[: K * M].copy_(records.reshape(-1))
+        pack[K * M : K * M + 4].copy_(self._flags)
+        pack[K * M + 4 :].copy_(self._control)
+
+    def _secure_reduce(self, records: torch.Tensor, lo: int, G: int) -> None:
+        """FedAvg under pairwise masking (reference capability: the share sums of
+        nanofed/server/aggregator/privacy.py:72-110 and the masked sums of
+        secure.py:192-313).  Client k submits share_k * theta_k blinded with one
+        seeded mask per peer (+ towards larger ids, - towards smaller ones), where
+        share_k = n_k / sum of all registered n.  The sum over the present
+        clients is taken with weight 1, the masks a missing client left without
+        partner are removed from the reduced sum on the device, and the result is
+        divided by the sum of the present shares."""
+        cfg, comm = self.cfg, self.comm
+        scale = cfg.secure_mask_scale
+        offset = self.round_id
+        table = self._secure_seed_table
+        for k, cid in enumerate(self.client_ids):
+            peers = [j for j in range(self._K) if j != cid]
+            ops.pairwise_mask_(
+                self.pool[k].data, [int(table[cid, j]) for j in peers],
+                [1.0 if cid < j else -1.0 for j in peers], scale,
+                prescale=self._shares_host[cid], offset=offset,
+            )
+        present = (records[:, M_VALID] > 0).to(torch.float32)
+        ops.weighted_sum(self.pool.rows(), present[lo : lo + G], out=self._partial)
+        comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
+        ops.pairwise_repair_(self._partial, present, self._secure_seeds, scale, offset=offset)
+        mass = (present * self._shares).sum().clamp(min=1e-30)
+        self._partial.div_(mass)
 
     # -- reporting / persistence ------------------------------------------
     def _report(
@@ -336,6 +668,7 @@ class FederatedEngine:
                 },
                 "weight": float(w[cid]),
                 "valid": bool(mask[cid]),
+                "update_norm": float(np.sqrt(max(rec[cid, M_UPDATE_SQNORM], 0.0))),
             }
             for cid in range(rec.shape[0])
         ]
@@ -350,10 +683,50 @@ class FederatedEngine:
             wall_s=wall,
         )
 
+    def _snapshot(self) -> tuple[torch.Tensor, object]:
+        """Host copy of the global arena for the writer: a device->pinned copy on
+        the side stream, ordered after the round's select by an event; the training
+        stream does not wait for it (the next round only reads the arena)."""
+        slot = self._snap_next
+        self._snap_next = (slot + 1) % len(self._snap_slots)
+        buf = self._snap_slots[slot]
+        if self._copy_stream is None:
+            buf.copy_(self.global_arena.data)
+            return buf, None
+        main = torch.cuda.current_stream(self.device)
+        self._copy_stream.wait_stream(main)
+        with torch.cuda.stream(self._copy_stream):
+            buf.copy_(self.global_arena.data, non_blocking=True)
+            self._snap_events[slot].record()
+        # the arena must not be overwritten (next round's select) before the copy ran
+        main.wait_event(self._snap_events[slot])
+        return buf, self._snap_events[slot]
+
     def _persist(self, report: RoundReport) -> None:
         if self._model_manager is None:
             return
-        self._host_model.load_state_dict(self.global_state_dict())
+        self._retire_stale_checkpoints()
+        if self._persister is not None:
+            # a free snapshot buffer is guaranteed by the bounded queue: wait for
+            # the writer before reusing the oldest one
+            while self._persister._jobs.full():
+                self._persister._jobs.join()
+        buf, event = self._snapshot()
+        job = {
+            "report": report, "flat": buf, "event": event, "next_round": self.round_id,
+            "phases_ms": dict(report.phases_ms),
+        }
+        if self._persister is not None:
+            self._persister.submit(job)
+        else:
+            self._write_job(job)
+
+    def _write_job(self, job: dict) -> None:
+        report: RoundReport = job["report"]
+        if job["event"] is not None:
+            job["event"].synchronize()
+        state = ParameterArena(self.layout, data=job["flat"]).state_dict("cpu")
+        self._host_model.load_state_dict(state)
         self._model_manager.save_model(
             config={
                 "round_id": report.round_id,
@@ -368,7 +741,8 @@ class FederatedEngine:
             metrics=report.agg_metrics,
         )
         path = self.base_dir / "metrics" / f"metrics_round_{report.round_id}.json"
-        with path.open("w") as f:
+        tmp = path.with_suffix(".json.tmp")
+        with tmp.open("w") as f:
             json.dump(
                 {
                     "round_id": report.round_id,
@@ -378,10 +752,11 @@ class FederatedEngine:
                     "agg_metrics": report.agg_metrics,
                     "status": report.status,
                     "client_metrics": report.client_metrics,
-                    "phases_ms": report.phases_ms,
+                    "phases_ms": job["phases_ms"],
                 },
                 f, indent=4,
             )
+        os.replace(tmp, path)
         if self._recovery is not None:
             from nanofed_amd.server.fault_tolerance import RoundState
 
@@ -390,9 +765,63 @@ class FederatedEngine:
                 report.round_id,
                 {},  # client models stay on the device; the global state is enough to resume
                 version.version_id if version is not None else "",
-                {"model_state": self.global_state_dict(), "next_round": self.round_id},
+                {"model_state": state, "next_round": job["next_round"]},
                 RoundState.COMPLETED,
             )
+
+    def _retire_stale_checkpoints(self) -> None:
+        """A fresh (not resumed) run must not recover into an older run's
+        checkpoints that happen to live under the same directory: they are moved
+        aside, once, before this run writes or reads its first checkpoint."""
+        if self._stale_checked or self._recovery is None:
+            return
+        self._stale_checked = True
+        if self._resumed:
+            return
+        ck = self.base_dir / "checkpoints"
+        if ck.exists() and any(ck.glob("round_*")):
+            stamp = get_current_time().strftime("%Y%m%d_%H%M%S")
+            target = self.base_dir / f"checkpoints.stale-{stamp}"
+            n = 0
+            while target.exists():
+                n += 1
+                target = self.base_dir / f"checkpoints.stale-{stamp}-{n}"
+            ck.rename(target)
+            ck.mkdir()
+            self.logger.warning(f"Moved checkpoints of an earlier run to {target.name}")
+
+    def flush(self) -> None:
+        """Wait until every submitted round is on disk (raises what the writer
+        thread raised)."""
+        if self._persister is not None:
+            self._persister.flush()
+
+    def close(self) -> None:
+        if self._watchdog is not None:
+            self._watchdog.close()
+        if self._persister is not None:
+            self._persister.close()
+            self._persister = None
+
+    def _on_round_timeout(self, round_id: int, limit_s: float) -> None:
+        msg = f"Round {round_id} exceeded its time limit of {limit_s:g} s"
+        try:
+            self.logger.error(msg + f"; ending the process with status {WATCHDOG_EXIT_CODE}")
+            if self.base_dir is not None and self.comm.is_root:
+                (self.base_dir / "metrics").mkdir(parents=True, exist_ok=True)
+                path = self.base_dir / "metrics" / f"metrics_round_{round_id}.json"
+                with path.open("w") as f:
+                    json.dump(
+                        {
+                            "round_id": round_id, "status": "FAILED", "num_clients": 0,
+                            "agg_metrics": {}, "client_metrics": [],
+                            "end_time": get_current_time().isoformat(),
+                            "error": f"TimeoutError: {msg}",
+                        },
+                        f, indent=4,
+                    )
+        finally:
+            os._exit(WATCHDOG_EXIT_CODE)
 
     # -- public helpers ---------------------------------------------------
     def run(self, num_rounds: int | None = None) -> list[RoundReport]:
@@ -400,26 +829,53 @@ class FederatedEngine:
         quorum.  A recoverable exception inside a round (``RuntimeError`` is how
         HIP and RCCL errors surface; reference: nanofed/server/fault_tolerance.py
         :139-152) rolls the global model back to the last completed checkpoint and
-        repeats from there, at most ``max_recoveries`` times."""
+        repeats from there, at most ``max_recoveries`` times.  In a multi-rank job
+        the exception every rank sees is ``RoundFailure``, raised after the round's
+        collectives, so the recovery collectives match on all ranks."""
         out: list[RoundReport] = []
         target = num_rounds if num_rounds is not None else self.cfg.num_rounds
-        while len(out) < target:
-            try:
-                out.append(self.run_round())
-            except Exception as failure:  # noqa: BLE001 - the strategy decides
-                if not self._recover(failure):
-                    raise
+        self._in_run = True
+        try:
+            while len(out) < target:
+                try:
+                    out.append(self.run_round())
+                except Exception as failure:  # noqa: BLE001 - the strategy decides
+                    cause = failure
+                    if isinstance(failure, RoundFailure) and failure.local is not None:
+                        cause = failure.local
+                    if not self._recover(failure):
+                        if cause is failure:
+                            raise
+                        raise cause from failure
+                    # rounds after the recovery point are repeated: drop their reports
+                    out = [rep for rep in out if rep.round_id < self.round_id]
+        finally:
+            self._in_run = False
+        self.flush()
         return out
 
     def _recover(self, failure: Exception) -> bool:
         """Every rank takes the same decision: rank 0 owns the checkpoints, the
-        restored arena and round counter are broadcast."""
+        restored arena and round counter are broadcast.  The trainers keep no
+        state across rounds (step counters, noise offsets and the privacy spent
+        are functions of the round number), so restoring the arena and the
+        counter restores the run."""
         if not self.cfg.checkpoint_rounds or self.recoveries >= self.cfg.max_recoveries:
             return False
         self.recoveries += 1
         self._timer.collect()
+        self._tail_graph = None  # recaptured on a quiet round
+        self._tail_rounds = 0
+        if self._persister is not None:
+            try:
+                self._persister.flush()
+            except Exception:  # noqa: BLE001 - the failure being handled
+                pass
         flag = torch.zeros(2, dtype=torch.float32, device=self.device)
         if self.comm.is_root and self._recovery is not None:
+            self._retire_stale_checkpoints()
+            # a failure that only a peer saw is recoverable by construction
+            # (it reached us as RoundFailure, a RuntimeError)
             restored = self._recovery.handle_failure(failure, self.round_id)
             if restored is not None:
                 _, state = restored
@@ -427,7 +883,8 @@ class FederatedEngine:
                 flag[0] = 1.0
                 flag[1] = float(state.get("next_round", self.round_id))
             elif self._recovery.is_recoverable(failure):
-                # nothing completed yet: the untouched initial model is the recovery point
+                # nothing completed yet: the model the failed round started from
+                self.global_arena.data.copy_(self._round_start)
                 flag[0] = 1.0
                 flag[1] = float(self.round_id)
         self.comm.broadcast(flag, src=0)
@@ -445,6 +902,7 @@ class FederatedEngine:
         and take the round counter from its config (the reference always
         restarts at round 0, nanofed/server/model_manager/manager.py:144-188).
         Returns the round the engine will run next."""
+        self._resumed = True
         state = torch.zeros(1, dtype=torch.float32, device=self.device)
         if self.comm.is_root and self._model_manager is not None:
             versions = self._model_manager.list_versions()

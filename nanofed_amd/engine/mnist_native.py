@@ -111,6 +111,17 @@ def _lib():
     return lib
 
 
+def supports(cfg: EngineConfig) -> bool:
+    """True when the hand-written kernels cover ``cfg`` (the engine's ``auto``
+    backend then takes this trainer instead of the PyTorch one)."""
+    return (
+        cfg.model == "mnist_cnn"
+        and cfg.batch_size == BATCH
+        and (cfg.dp is None or cfg.dp.mode == "per_sample")
+        and not cfg.model_kwargs
+    )
+
+
 def native_permutations() -> dict[str, torch.Tensor]:
     """stored_flat = canonical_flat[perm] for the two re-ordered tensors."""
     conv2 = torch.arange(64 * 32 * 9).view(64, 32, 3, 3).permute(0, 2, 3, 1).reshape(-1)
@@ -385,6 +396,13 @@ class MnistCnnNativeTrainer(GroupTrainer):
         self._sizes = torch.tensor(
             [float(s) for s in shards.sizes], dtype=torch.float32, device=self.device
         )
+        # optimisation steps a client takes per local epoch: its step counter (which
+        # numbers the dropout and noise streams) restarts every round from
+        # round * local_epochs * steps, so a rolled-back or resumed run draws the
+        # same streams as an uninterrupted one and nothing has to be checkpointed
+        self._steps_per_epoch = torch.tensor(
+            [shards.steps_per_epoch(k) for k in range(G)], dtype=torch.int64, device=self.device
+        )
 
     @staticmethod
     def _group_sizes(G: int) -> list[int]:
@@ -511,6 +529,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
         cfg = self.cfg
         self._ensure_graph(round_idx)
         self.buf.pack()
+        torch.mul(self._steps_per_epoch, round_idx * cfg.local_epochs, out=self.buf.step_counter)
         for epoch in range(cfg.local_epochs):
             self._take_indices(round_idx, epoch)
             self.buf.metrics.zero_()
@@ -526,12 +545,15 @@ class MnistCnnNativeTrainer(GroupTrainer):
         out[:, M_ACC] = m[:, 1] / batches
         out[:, M_VALID] = 1.0
         if self._accountants is not None:
-            # privacy spent is a pure function of the number of noisy steps
-            eps = []
-            for k, acc in enumerate(self._accountants):
-                for _ in range(cfg.local_epochs * self.shards.steps_per_epoch(k)):
-                    acc.add_noise_event(cfg.dp.noise_multiplier, BATCH)
-                eps.append(acc.get_privacy_spent().epsilon_spent)
+            # privacy spent is a pure function of the number of noisy steps taken
+            # since round 0: one closed-form evaluation per client and round
+            eps = [
+                acc.epsilon_after(
+                    (round_idx + 1) * cfg.local_epochs * self.shards.steps_per_epoch(k),
+                    cfg.dp.noise_multiplier, BATCH,
+                )
+                for k, acc in enumerate(self._accountants)
+            ]
             out[:, M_EPSILON] = torch.tensor(eps, dtype=torch.float32).to(self.device)
         return out
 

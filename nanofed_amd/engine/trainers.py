@@ -134,10 +134,11 @@ class TorchGroupTrainer(GroupTrainer):
             ns = max(1, min(len(pool), ns))
             base = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
             self._streams = [base[k % ns] for k in range(len(pool))]
-        if self._channels_last:
-            # let the convolution library time its kernels per shape once (during
-            # the eager warm-up steps) instead of taking its untuned default
-            torch.backends.cudnn.benchmark = True
+        # The convolution library times its kernels per shape once (during the
+        # eager warm-up steps) instead of taking its untuned default.  The flag is
+        # process-global in PyTorch, so it is switched on only around this trainer's
+        # own work (train_round / evaluate) and put back afterwards.
+        self._autotune = self._channels_last
 
     def _bind_shadow(self) -> None:
         layout = self.pool.layout
@@ -205,11 +206,17 @@ class TorchGroupTrainer(GroupTrainer):
         static_rows = (
             torch.arange(self.cfg.batch_size, device=self.device) + int(self.shards.offsets[k])
         )
-        side = torch.cuda.Stream()
+        side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
                 self._eager_step(k, static_rows)
+            # the ragged last batch of an epoch is a shape of its own: let the
+            # convolution library tune it now, not in the middle of a round while
+            # the other clients' graphs replay
+            tail = self.shards.sizes[k] % self.cfg.batch_size
+            if tail and not self.shards.drop_last:
+                self._eager_step(k, static_rows[:tail])
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -265,9 +272,22 @@ class TorchGroupTrainer(GroupTrainer):
         )
 
     def train_round(self, round_idx: int) -> torch.Tensor:
+        if not self._autotune:
+            return self._train_round(round_idx)
+        previous = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        try:
+            return self._train_round(round_idx)
+        finally:
+            torch.backends.cudnn.benchmark = previous
+
+    def _train_round(self, round_idx: int) -> torch.Tensor:
         cfg = self.cfg
         G = len(self.pool)
         self.metrics.zero_()
+        # the noise offsets of a round are a function of the round number (a
+        # rolled-back round draws the same noise as the run that never failed)
+        self._dp_step = round_idx * cfg.local_epochs * max(self.shards.max_steps(), 1) * max(G, 1)
         if self._direct:
             self._refresh_shadow()
         if self._streams is not None and G > 1:

@@ -14,8 +14,13 @@ from .arena_ops import (
     MODE_UNIFORM,
     clip_noise,
     l2_norm,
+    pairwise_mask_,
+    pairwise_repair_,
     philox_fill,
+    round_weights,
     scale_accumulate,
+    screen_rows,
+    select_copy,
     sgd_multi,
     sgd_step,
     sqnorm_finite,
@@ -51,8 +56,13 @@ __all__ = [
     "hip_lib",
     "l2_norm",
     "mask_add_",
+    "pairwise_mask_",
+    "pairwise_repair_",
     "philox_fill",
+    "round_weights",
     "scale_accumulate",
+    "screen_rows",
+    "select_copy",
     "sgd_multi",
     "sgd_step",
     "sqnorm_finite",

@@ -16,6 +16,15 @@ Operations and the reference behaviour they replace:
 ``sgd_step``          p -= lr * (g + wd * p)              (torch.optim.SGD in nanofed/trainer/base.py:150)
 ``philox_fill``       counter-based uniform/normal/laplace (nanofed/privacy/noise/generators.py:49-67)
 ``scale_accumulate``  out = a * out + b * in              (mask add / unmask, nanofed/server/aggregator/secure.py:230-296)
+``screen_rows``       finite / norm verdict of every client row in two launches
+                                                         (nanofed/server/validation.py:84-101 per update)
+``round_weights``     z-score anomaly screen + n_k / sum(n) weights + quorum flag on device
+                                                         (nanofed/server/validation.py:103-135,
+                                                          nanofed/server/aggregator/fedavg.py:101-125,
+                                                          nanofed/orchestration/coordinator.py:209-236)
+``select_copy``       dst = src when a device flag is set (the old model survives a failed round)
+``pairwise_mask`` / ``pairwise_repair``  seeded pairwise blinding of a row, removal of the
+                      masks a dropped client left unmatched (nanofed/server/aggregator/secure.py:192-313)
 """
 
 from __future__ import annotations
@@ -385,6 +394,223 @@ def scale_accumulate(out: torch.Tensor, inp: torch.Tensor, a: float, b: float) -
         "nf_scale_accumulate",
     )
     return out
+
+
+# ---------------------------------------------------------------------------
+_screen_ws: dict[tuple[int, int, int], torch.Tensor] = {}
+
+
+def screen_rows(
+    rows: torch.Tensor,
+    records: torch.Tensor,
+    col_sq: int,
+    col_valid: int,
+    ref: torch.Tensor | None = None,
+    max_norm: float = 0.0,
+) -> torch.Tensor:
+    """Screen the G client rows of a pool (``rows`` is ``[G, n]``, rows may be
+    strided) in two launches: ``records[g, col_sq]`` receives the squared L2 norm
+    of row g (of ``row - ref`` when ``ref`` is given) over its finite entries and
+    ``records[g, col_valid]`` is zeroed when the row holds a non-finite value or,
+    with ``max_norm > 0``, its norm exceeds the bound."""
+    if rows.dim() != 2 or records.dim() != 2 or records.shape[0] < rows.shape[0]:
+        raise DeviceError("screen_rows: rows [G, n] and records [>=G, M] are required")
+    G, n = rows.shape
+    dev = rows.device
+    max_sq = float(max_norm) ** 2 if max_norm > 0 else 0.0
+    if dev.type != "cuda":
+        x = rows.to(torch.float32)
+        if ref is not None:
+            x = x - ref.to(torch.float32)
+        ok = torch.isfinite(x)
+        sq = torch.where(ok, x, torch.zeros_like(x)).square().sum(dim=1)
+        valid = ok.all(dim=1)
+        if max_sq > 0:
+            valid = valid & (sq <= max_sq)
+        records[:G, col_sq] = sq
+        records[:G, col_valid] = records[:G, col_valid] * valid.to(records.dtype)
+        return records
+    if rows.dtype != torch.float32 or rows.stride(1) != 1 or rows.data_ptr() % 16:
+        raise DeviceError("screen_rows: rows must be float32, unit inner stride, 16-byte aligned")
+    library.require_flat_f32(records, "screen_rows records", align=4)
+    if ref is not None:
+        library.require_flat_f32(ref, "screen_rows reference")
+        if ref.numel() != n:
+            raise DeviceError("screen_rows: reference length differs from the rows")
+    lib = library.hip_lib()
+    key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream, G)
+    ws = _screen_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.nf_screen_workspace_floats(G)), dtype=torch.float32, device=dev)
+        _screen_ws[key] = ws
+    library.check(
+        lib.nf_screen_rows(
+            _ptr(rows), c_int(G), c_long(rows.stride(0)), c_long(n),
+            _ptr(ref) if ref is not None else c_void_p(0), _ptr(ws), _ptr(records),
+            c_int(records.stride(0)), c_int(col_sq), c_int(col_valid), c_float(max_sq),
+            library.stream_ptr(dev),
+        ),
+        "nf_screen_rows",
+    )
+    return records
+
+
+def round_weights(
+    records: torch.Tensor,
+    col_samples: int,
+    col_valid: int,
+    col_sq: int,
+    required: float,
+    weights: torch.Tensor,
+    flags: torch.Tensor,
+    z_threshold: float = 0.0,
+    min_clients_for_stats: int = 5,
+) -> None:
+    """From the gathered ``[K, M]`` client records, on the device: optional
+    leave-one-out z-score screen of the update norms (a client more than
+    ``z_threshold`` standard deviations from the mean of the other valid clients
+    is marked invalid in ``records``), ``weights[k] = valid_k n_k / sum(valid n)``
+    and ``flags = [round ok, valid clients, total samples, anomalous clients]``."""
+    K, M = records.shape
+    if weights.numel() < K or flags.numel() < 4:
+        raise DeviceError("round_weights: weights [K] and flags [4] are required")
+    dev = records.device
+    if dev.type != "cuda":
+        valid = records[:, col_valid] > 0
+        anomalous = 0
+        if z_threshold > 0:
+            x = records[:, col_sq].to(torch.float64).sqrt()
+            m = int(valid.sum())
+            others = m - 1
+            if others >= min_clients_for_stats and others >= 2:
+                S = x[valid].sum()
+                Q = x[valid].square().sum()
+                mean = (S - x) / others
+                var = ((Q - x * x - others * mean * mean) / (others - 1)).clamp(min=0.0)
+                z = (x - mean).abs() / (var.sqrt() + 1e-8)
+                bad = valid & (z > z_threshold)
+                anomalous = int(bad.sum())
+                records[:, col_valid] = torch.where(
+                    bad, torch.zeros_like(records[:, col_valid]), records[:, col_valid]
+                )
+                valid = records[:, col_valid] > 0
+        v = valid.to(torch.float32)
+        mass = v * records[:, col_samples]
+        total = mass.sum()
+        weights[:K] = mass / total.clamp(min=1e-30)
+        flags[0] = float(bool(v.sum() >= required) and bool(total > 0))
+        flags[1] = v.sum()
+        flags[2] = total
+        flags[3] = float(anomalous)
+        return
+    library.require_flat_f32(records, "round_weights records", align=4)
+    library.require_flat_f32(weights, "round_weights weights", align=4)
+    library.require_flat_f32(flags, "round_weights flags", align=4)
+    library.check(
+        library.hip_lib().nf_round_weights(
+            _ptr(records), c_int(K), c_int(M), c_int(col_samples), c_int(col_valid),
+            c_int(col_sq), c_float(required), c_float(z_threshold),
+            c_int(min_clients_for_stats), _ptr(weights), _ptr(flags), library.stream_ptr(dev),
+        ),
+        "nf_round_weights",
+    )
+
+
+def select_copy(dst: torch.Tensor, src: torch.Tensor, flag: torch.Tensor) -> torch.Tensor:
+    """``dst = src`` when ``flag[0] > 0`` (decided on the device)."""
+    _same_flat([dst, src], "select_copy")
+    if dst.device.type != "cuda":
+        if bool(flag.reshape(-1)[0] > 0):
+            dst.copy_(src)
+        return dst
+    library.require_flat_f32(dst, "select_copy dst")
+    library.require_flat_f32(src, "select_copy src")
+    library.check(
+        library.hip_lib().nf_select_copy(
+            _ptr(dst), _ptr(src), _ptr(flag), c_long(dst.numel()),
+            library.stream_ptr(dst.device),
+        ),
+        "nf_select_copy",
+    )
+    return dst
+
+
+def pairwise_mask_(
+    row: torch.Tensor,
+    seeds: Sequence[int],
+    signs: Sequence[float],
+    scale: float,
+    prescale: float = 1.0,
+    offset: int = 0,
+) -> torch.Tensor:
+    """``row = prescale * row + sum_p signs[p] * scale * U_p`` where ``U_p`` is the
+    symmetric-uniform Philox stream of ``seeds[p]`` (what ``mask_add_`` draws): a
+    client's blinding against all its peers in one pass."""
+    if row.dim() != 1 or len(seeds) != len(signs):
+        raise DeviceError("pairwise_mask_: a flat row and one sign per seed are required")
+    if row.device.type != "cuda":
+        row.mul_(prescale)
+        for seed, sign in zip(seeds, signs):
+            philox_fill(row, seed, offset, MODE_SYM_UNIFORM, scale=sign * scale, accumulate=True)
+        return row
+    library.require_flat_f32(row, "pairwise_mask_ row")
+    lib = library.hip_lib()
+    cap = int(lib.nf_max_peers())
+    first = True
+    for lo in range(0, max(len(seeds), 1), cap):
+        chunk = list(seeds[lo : lo + cap])
+        sg = list(signs[lo : lo + cap])
+        s_arr = (c_ulonglong * max(len(chunk), 1))(*[s & (2**64 - 1) for s in chunk])
+        f_arr = (c_float * max(len(chunk), 1))(*sg)
+        library.check(
+            lib.nf_pairwise_mask(
+                _ptr(row), c_long(row.numel()), c_float(prescale if first else 1.0), s_arr,
+                f_arr, c_int(len(chunk)), c_float(scale), c_ulonglong(offset & (2**64 - 1)),
+                library.stream_ptr(row.device),
+            ),
+            "nf_pairwise_mask",
+        )
+        first = False
+    return row
+
+
+def pairwise_repair_(
+    total: torch.Tensor,
+    present: torch.Tensor,
+    seeds: torch.Tensor,
+    scale: float,
+    offset: int = 0,
+) -> torch.Tensor:
+    """Remove from a sum of blinded rows the masks that found no partner: for
+    every pair with exactly one present client, subtract what the survivor added.
+    ``present`` is ``[K]`` floats and ``seeds`` ``[K, K]`` int64 on ``total``'s
+    device, so the decision needs no host round trip."""
+    K = present.numel()
+    if seeds.shape != (K, K) or seeds.dtype != torch.int64:
+        raise DeviceError("pairwise_repair_: seeds must be a [K, K] int64 table")
+    if total.device.type != "cuda":
+        pres = [bool(v > 0) for v in present.tolist()]
+        table = seeds.tolist()
+        for i in range(K):
+            for j in range(i + 1, K):
+                if pres[i] == pres[j]:
+                    continue
+                a = scale if pres[i] else -scale
+                philox_fill(total, table[i][j], offset, MODE_SYM_UNIFORM, scale=-a,
+                            accumulate=True)
+        return total
+    library.require_flat_f32(total, "pairwise_repair_ total")
+    library.require_flat_f32(present, "pairwise_repair_ present", align=4)
+    if not seeds.is_contiguous():
+        raise DeviceError("pairwise_repair_: seeds must be contiguous")
+    library.check(
+        library.hip_lib().nf_pairwise_repair(
+            _ptr(total), c_long(total.numel()), _ptr(present), _ptr(seeds), c_int(K),
+            c_float(scale), c_ulonglong(offset & (2**64 - 1)), library.stream_ptr(total.device),
+        ),
+        "nf_pairwise_repair",
+    )
+    return total
 
 
 def l2_norm(x: torch.Tensor) -> float:

@@ -47,6 +47,13 @@ def _signatures() -> dict:
         "nf_sgd_multi": ([P, P, P, P, P, P, I, F, F, P], I),
         "nf_philox_fill": ([P, L, U, U, L, I, F, I, P], I),
         "nf_scale_accumulate": ([P, P, L, F, F, P], I),
+        "nf_screen_workspace_floats": ([I], I),
+        "nf_max_peers": ([], I),
+        "nf_screen_rows": ([P, I, L, L, P, P, P, I, I, I, F, P], I),
+        "nf_round_weights": ([P, I, I, I, I, I, F, F, I, P, P, P], I),
+        "nf_select_copy": ([P, P, P, L, P], I),
+        "nf_pairwise_mask": ([P, L, F, P, P, I, F, U, P], I),
+        "nf_pairwise_repair": ([P, L, P, P, I, F, U, P], I),
     }
 
 

@@ -126,6 +126,24 @@ class SubsampledRDPAccountant(BasePrivacyAccountant):
         self._rdp = [r + d for r, d in zip(self._rdp, inc)]
         self._event_count += 1
 
+    def epsilon_after(self, events: int, sigma: float, samples: int) -> float:
+        """Epsilon spent by ``events`` identical noise events, in closed form: RDP
+        composes additively, so ``events`` steps cost ``events`` times one step at
+        every order.  Nothing is recorded; a trainer whose step count is a function
+        of the round number asks this once per round instead of replaying events."""
+        check_event(sigma, samples)
+        if events <= 0:
+            return 0.0
+        q = min(samples / self._dataset_size, 1.0)
+        inc = self._cache.get((q, sigma))
+        if inc is None:
+            inc = [subsampled_gaussian_rdp(q, sigma, a) for a in self._orders]
+            self._cache[(q, sigma)] = inc
+        delta = self._config.delta
+        return min(
+            events * d + math.log(1 / delta) / (a - 1) for d, a in zip(inc, self._orders)
+        )
+
     def _compute_privacy_spent(self) -> PrivacySpent:
         if self._event_count == 0:
             return PrivacySpent(0.0, 0.0)

@@ -1,0 +1,199 @@
+"""Multi-process rehearsals on CPU (gloo): ``bench.py`` itself under
+``torch.distributed.run`` at 4 and 8 ranks, 8 clients on 3 ranks (uneven
+placement), a failure that only one rank sees, and a stalled rank that the
+round watchdog ends."""
+
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+from nanofed_amd.engine import EngineConfig, FederatedEngine
+from nanofed_amd.engine.federation import WATCHDOG_EXIT_CODE
+from nanofed_amd.parallel import Communicator
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.update(extra)
+    return env
+
+
+BENCH_ARGS = ["--cpu", "--steps", "2", "--warmup", "1", "--model", "mnist_mlp",
+              "--samples-per-client", "64", "--batch-size", "32", "--backend", "torch",
+              "--dtype", "fp32", "--eval-samples", "64", "--local-epochs", "1"]
+
+
+def _bench(nproc: int, dump: str) -> dict:
+    args = BENCH_ARGS + ["--gpus", str(nproc), "--dump-model", dump]
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {lines!r}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("nproc", [4, 8])
+def test_bench_under_the_launcher_prints_one_json_line_and_the_same_model(tmp_path, nproc):
+    single = _bench(1, str(tmp_path / "one.pt"))
+    multi = _bench(nproc, str(tmp_path / "many.pt"))
+    assert single["n_gpus"] == 1 and multi["n_gpus"] == nproc
+    for line in (single, multi):
+        assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
+        assert line["higher_is_better"] is True and line["scaling"] == "strong"
+        assert line["config"]["clients"] == 8
+        assert line["rounds_per_s_no_persistence"] > 0
+    assert multi["config"]["parallelism"] == f"fed8/gpu{nproc}"
+    a = torch.load(tmp_path / "one.pt", weights_only=True)
+    b = torch.load(tmp_path / "many.pt", weights_only=True)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert multi["final_train_loss"] == pytest.approx(single["final_train_loss"], rel=1e-4)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = _env(WORLD_SIZE="2", RANK="0", MASTER_PORT=str(_free_port()))
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu", "--gpus", "4"],
+        capture_output=True, text=True, timeout=120, env=env, cwd=ROOT,
+    )
+    assert proc.returncode == 2 and "does not match" in proc.stderr
+    assert proc.stdout.strip() == ""
+
+
+WORKER = r"""
+import sys, json, time, torch
+sys.path.insert(0, {root!r})
+from nanofed_amd.engine import EngineConfig, FaultPlan, FederatedEngine
+from nanofed_amd.parallel import Communicator
+comm = Communicator.from_env(backend="gloo", device="cpu")
+cfg = EngineConfig(**{cfg!r})
+faults = FaultPlan(**{faults!r})
+eng = FederatedEngine(cfg, comm=comm, base_dir={base!r} if comm.is_root else None, faults=faults)
+if {resume!r}:
+    eng.resume()
+reps = eng.run({rounds!r})
+if comm.is_root:
+    torch.save({{"flat": eng.global_arena.data, "rounds": [r.round_id for r in reps],
+                "status": [r.status for r in reps], "recoveries": eng.recoveries,
+                "weights": [c["weight"] for c in reps[-1].client_metrics],
+                "loss": reps[-1].agg_metrics["loss"]}}, {out!r})
+eng.close()
+comm.close()
+"""
+
+BASE_CFG = dict(model="mnist_mlp", num_clients=8, samples_per_client=[96, 64, 64, 32, 64, 64, 96, 32],
+                batch_size=32, local_epochs=1, eval_samples=64, dtype="fp32", backend="torch",
+                model_kwargs={"hidden": 16}, learning_rate=0.1)
+
+
+def _launch(tmp_path, nproc, cfg, faults=None, rounds=2, base=None, resume=False, name="w"):
+    out = tmp_path / f"{name}.pt"
+    script = tmp_path / f"{name}.py"
+    script.write_text(WORKER.format(root=ROOT, cfg=cfg, faults=faults or {}, base=base,
+                                    resume=resume, rounds=rounds, out=str(out)))
+    port = _free_port()
+    procs = []
+    for rank in range(nproc):
+        env = _env(RANK=str(rank), WORLD_SIZE=str(nproc), LOCAL_RANK=str(rank),
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    return procs, out
+
+
+def _wait(procs, timeout):
+    deadline = time.monotonic() + timeout
+    codes = []
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("worker processes did not end in time")
+        codes.append(p.returncode)
+    return codes
+
+
+def test_eight_clients_on_three_ranks_equal_the_single_process_run(tmp_path):
+    procs, out = _launch(tmp_path, 3, BASE_CFG)
+    codes = _wait(procs, 300)
+    assert codes == [0, 0, 0], [p.stderr.read()[-1500:] for p in procs]
+    dist = torch.load(out, weights_only=False)
+    single = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
+    reps = single.run(2)
+    torch.testing.assert_close(dist["flat"], single.global_arena.data, rtol=1e-5, atol=1e-6)
+    assert dist["weights"] == pytest.approx([c["weight"] for c in reps[-1].client_metrics])
+    assert dist["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-4)
+
+
+def test_a_failure_on_one_rank_only_is_agreed_on_and_recovered_by_all(tmp_path):
+    cfg = dict(BASE_CFG, checkpoint_rounds=True)
+    # only rank 1 raises, in the middle of round 1; rank 0 finishes its training
+    faults = dict(fail={1: "HIP error: injected on one rank"}, fail_ranks={1})
+    procs, out = _launch(tmp_path, 2, cfg, faults=faults, rounds=3, base=str(tmp_path / "run"))
+    codes = _wait(procs, 300)
+    assert codes == [0, 0], [p.stderr.read()[-1500:] for p in procs]
+    dist = torch.load(out, weights_only=False)
+    assert dist["recoveries"] == 1
+    assert dist["rounds"] == [0, 1, 2] and dist["status"] == ["COMPLETED"] * 3
+    clean = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
+    clean.run(3)
+    torch.testing.assert_close(dist["flat"], clean.global_arena.data, rtol=1e-5, atol=1e-6)
+
+
+def test_a_failure_on_one_rank_without_checkpoints_ends_every_rank(tmp_path):
+    faults = dict(fail={0: "RCCL error: injected"}, fail_ranks={0})
+    procs, _ = _launch(tmp_path, 2, BASE_CFG, faults=faults, rounds=2)
+    codes = _wait(procs, 300)
+    errs = [p.stderr.read() for p in procs]
+    assert all(c != 0 for c in codes)
+    assert "RCCL error: injected" in errs[0]
+    assert "RoundFailure" in errs[1] and "rank(s) [0]" in errs[1]
+
+
+def test_a_stalled_rank_ends_the_job_within_the_timeout_and_resume_continues(tmp_path):
+    base = tmp_path / "run"
+    cfg = dict(BASE_CFG, round_timeout_s=3.0, enforce_round_timeout=True, first_round_grace_s=60.0)
+    # rank 1 hangs for two minutes inside round 1; round 0 completes and is saved
+    faults = dict(stall={1: {1: 120.0}})
+    t0 = time.monotonic()
+    procs, _ = _launch(tmp_path, 2, cfg, faults=faults, rounds=3, base=str(base))
+    codes = _wait(procs, 100)
+    assert time.monotonic() - t0 < 90
+    assert codes == [WATCHDOG_EXIT_CODE, WATCHDOG_EXIT_CODE], [p.stderr.read()[-1500:] for p in procs]
+    failed = json.loads((base / "metrics" / "metrics_round_1.json").read_text())
+    assert failed["status"] == "FAILED" and "TimeoutError" in failed["error"]
+    done = json.loads((base / "metrics" / "metrics_round_0.json").read_text())
+    assert done["status"] == "COMPLETED"
+    # a fresh job resumes after the last completed round
+    procs, out = _launch(tmp_path, 2, BASE_CFG, rounds=2, base=str(base), resume=True, name="again")
+    assert _wait(procs, 300) == [0, 0]
+    again = torch.load(out, weights_only=False)
+    assert again["rounds"] == [1, 2] and again["status"] == ["COMPLETED"] * 2
+    clean = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
+    clean.run(3)
+    torch.testing.assert_close(again["flat"], clean.global_arena.data, rtol=1e-5, atol=1e-6)
