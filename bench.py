@@ -149,6 +149,7 @@ def main() -> int:
             "persistence": "off" if args.no_persist else
             "model version (.pt + JSON) and metrics JSON per round, writer thread, flushed in the timed region",
             "rounds_per_s_no_persistence": (min(args.steps, 10) / bare) if bare else None,
+            "stream_set": (last.trainer_info or None) if last else None,
             "final_test_accuracy": final.get("accuracy"),
             "final_train_accuracy": last.agg_metrics["accuracy"] if last else None,
             "final_train_loss": last.agg_metrics["loss"] if last else None,

@@ -41,9 +41,12 @@ def engine_config(name: str, clients: int):
                             samples_per_client=1024, batch_size=64, local_epochs=1,
                             learning_rate=0.05, eval_samples=2000)
     if name == "gpt2_125m":
+        # the token chain lives on the first 2048 ids (the model keeps all 50257
+        # columns): 131k training tokens per round are enough to see it learned
         return EngineConfig(model="gpt2_125m", dataset="synthetic_tokens", num_clients=clients,
                             samples_per_client=16, batch_size=4, local_epochs=1, seq_len=1024,
-                            learning_rate=0.01, eval_samples=8)
+                            learning_rate=0.2, eval_samples=8, token_active_vocab=2048,
+                            gpt2_lanes=int(os.environ.get("NANOFED_GPT2_LANES", "1")))
     raise SystemExit(f"unknown config {name}")
 
 

@@ -93,7 +93,7 @@ struct MnistCtx {
     float* c2b_part;        // [G][72][64]
     float* head_part;       // [G][B/8][1440]
     float* metrics;         // [G][4] loss sum, accuracy sum, batches, -
-    float* eval_out;        // [2] loss sum, correct count (eval mode)
+    float* eval_out;        // [G][B/8][2] loss sum, correct count per workgroup of the last step (eval mode)
     unsigned long long* step_counter;  // [G] optimisation steps taken by each client
     unsigned long long seed;
     float lr, wd, mean, inv_std, p_drop1, p_drop2;
@@ -470,9 +470,12 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         for (int i = 0; i < kHeadRows; ++i) { loss_sum += red[0][i]; correct += red[1][i]; }
     }
     if (!c.train && c.eval_out != nullptr) {
+        // one slot per workgroup, overwritten every step: the host adds the slots of
+        // the clients that had a batch, in a fixed order (no float atomics)
         if (tid == 0) {
-            atomicAdd(c.eval_out + 0, loss_sum);
-            atomicAdd(c.eval_out + 1, correct);
+            float* e = c.eval_out + (static_cast<long>(g) * (c.B / kHeadRows) + hb) * 2;
+            e[0] = loss_sum;
+            e[1] = correct;
         }
         return;
     }

@@ -66,17 +66,27 @@ def synthetic_cifar10(num_samples: int = 50000, seed: int = 0):
 
 
 def synthetic_tokens(
-    num_sequences: int, seq_len: int = 1024, vocab_size: int = 50257, seed: int = 0
+    num_sequences: int, seq_len: int = 1024, vocab_size: int = 50257, seed: int = 0,
+    table_seed: int | None = None, active_vocab: int | None = None,
 ) -> torch.Tensor:
     """``int64 [N, seq_len+1]`` token ids from a sparse first-order Markov
-    chain (each token has 4 likely successors), so next-token loss can drop."""
+    chain (each token has 4 likely successors), so next-token loss can drop.
+
+    ``table_seed`` fixes the successor table separately from the sequences: a
+    held-out split drawn with another ``seed`` but the same ``table_seed`` follows
+    the same chain, so evaluating on it measures what training learned.
+    ``active_vocab`` confines the chain to the first ids of the vocabulary (the
+    model keeps its full embedding / LM-head width): with few training tokens a
+    chain over all 50257 ids cannot be learned, one over a few thousand can."""
     rng = np.random.default_rng(seed)
-    succ = rng.integers(0, vocab_size, size=(vocab_size, 4))
+    table_rng = np.random.default_rng(seed if table_seed is None else table_seed)
+    active = vocab_size if not active_vocab else min(int(active_vocab), vocab_size)
+    succ = table_rng.integers(0, active, size=(active, 4))
     toks = np.empty((num_sequences, seq_len + 1), dtype=np.int64)
-    toks[:, 0] = rng.integers(0, vocab_size, size=num_sequences)
+    toks[:, 0] = rng.integers(0, active, size=num_sequences)
     choice = rng.integers(0, 4, size=(num_sequences, seq_len))
     jump = rng.random(size=(num_sequences, seq_len)) < 0.1
-    rand = rng.integers(0, vocab_size, size=(num_sequences, seq_len))
+    rand = rng.integers(0, active, size=(num_sequences, seq_len))
     for t in range(seq_len):
         nxt = succ[toks[:, t], choice[:, t]]
         toks[:, t + 1] = np.where(jump[:, t], rand[:, t], nxt)

@@ -47,6 +47,9 @@ class EngineConfig:
     eval_samples: int = 10000
     data_dir: str = "./data"
     seq_len: int = 1024
+    # synthetic token streams: confine the Markov chain to the first ids of the
+    # vocabulary (0 = all of it); the model keeps its full width
+    token_active_vocab: int = 0
     # execution
     backend: str = "auto"  # auto | native | torch
     dtype: str = "bf16"  # compute dtype of the local trainers: bf16 | fp32

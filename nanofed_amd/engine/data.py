@@ -94,9 +94,11 @@ def build_federated_data(cfg: EngineConfig) -> FederatedData:
         return FederatedData("image", x, y, shards, ex, ey, mean, std)
     if cfg.dataset == "synthetic_tokens":
         vocab = int(cfg.model_kwargs.get("vocab_size", 50257))
-        toks = synthetic_tokens(total, cfg.seq_len, vocab, seed=cfg.seed)
+        toks = synthetic_tokens(total, cfg.seq_len, vocab, seed=cfg.seed,
+                                active_vocab=cfg.token_active_vocab)
         ev = synthetic_tokens(
-            max(cfg.eval_samples, 1), cfg.seq_len, vocab, seed=cfg.seed + 1
+            max(cfg.eval_samples, 1), cfg.seq_len, vocab, seed=cfg.seed + 1,
+            table_seed=cfg.seed, active_vocab=cfg.token_active_vocab,
         )
         shards = (
             iid_partition(total, cfg.num_clients, seed=cfg.seed)

@@ -98,6 +98,8 @@ class RoundReport:
     end_time: str
     wall_s: float
     phases_ms: dict[str, float] = field(default_factory=dict)
+    # what the local trainer wants on record (e.g. which stream set it chose)
+    trainer_info: dict = field(default_factory=dict)
 
 
 @dataclass
@@ -495,6 +497,7 @@ class FederatedEngine:
 
         report = self._report(r, rec, succeeded, start, time.perf_counter() - t0)
         report.phases_ms = phases
+        report.trainer_info = dict(getattr(self.trainer, "stream_report", None) or {})
         if flags[3] > 0:
             report.agg_metrics["anomalous_clients"] = float(flags[3])
         self.reports.append(report)
@@ -753,6 +756,7 @@ class FederatedEngine:
                     "status": report.status,
                     "client_metrics": report.client_metrics,
                     "phases_ms": job["phases_ms"],
+                    "trainer_info": report.trainer_info,
                 },
                 f, indent=4,
             )

@@ -9,14 +9,16 @@ trainer runs the step by hand on flat buffers:
   passes read a bf16 copy with the same offsets, refreshed by the SGD kernel, so
   no weight is cast per step;
 * gradients are written as bf16 straight into one flat gradient buffer by the
-  GEMMs (``torch.mm(..., out=view)``), then consumed by one SGD launch;
+  weight-gradient GEMMs, then consumed by one SGD launch;
 * everything between the GEMMs is a hand-written kernel
   (``nanofed_amd.ops.nn_ops`` / ``nanofed_amd.ops.attention``): embedding
   gather and its scatter-free backward, residual-add + LayerNorm, tanh-GELU,
   bias gradients, softmax cross-entropy that overwrites the logits with their
   gradient (the logits are never upcast), causal flash attention;
-* GEMMs go to hipBLASLt through ``torch.mm`` / ``torch.addmm`` (bias in the
-  GEMM epilogue).
+* GEMMs run on the hand-written MFMA kernels of ``nanofed_amd.ops.gemm_ops``
+  (forward, data-gradient and weight-gradient layouts without transposed copies,
+  bias and GELU in the forward epilogue); ``NANOFED_NATIVE_GEMM=0`` routes them to
+  hipBLASLt through ``torch.mm`` / ``torch.addmm`` instead, for comparison.
 
 Activations are bf16, statistics and losses fp32.  The G clients of a GPU are
 trained one after the other and share the activation and gradient buffers.
@@ -33,6 +35,7 @@ import torch.nn.functional as F
 from nanofed_amd.core.exceptions import DeviceError
 from nanofed_amd.models.gpt2 import GPT2Config
 from nanofed_amd.ops import attention as attn_ops
+from nanofed_amd.ops import gemm_ops
 from nanofed_amd.ops import nn_ops
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
 
@@ -108,25 +111,27 @@ class GPT2NativeTrainer(GroupTrainer):
         # Lanes: independent sets of activation / gradient buffers, one HIP stream
         # each; client k trains on lane k % lanes, so steps of different clients
         # overlap on the GPU (many kernels of a 4096-row step leave compute units
-        # idle): two lanes measured 3.45 -> 4.73 rounds/s.  FOUR lanes hung the
-        # process twice (no GPU fault), the second time with the one stream-K GEMM
-        # of the step - the LM-head forward, whose workgroups wait for each other
-        # through memory - serialised across lanes, so the cause is not understood.
-        # Lanes are therefore opt-in (EngineConfig.gpt2_lanes or NANOFED_GPT2_LANES=2),
-        # never more than two, and only for the step shape whose kernel trace was inspected (GPT-2
-        # small, 4096 rows per step, full batches); the default is one lane.
+        # idle).  With the GEMMs on the vendor library two lanes measured 3.45 -> 4.73
+        # rounds/s, but FOUR lanes hung the process twice (no GPU fault) and the
+        # cause was never shown - the library's stream-K / split-K GEMM kernels,
+        # whose workgroups wait for each other through memory, are the suspects, and
+        # they are issued from one host thread that shares one library handle.
+        # Every multi-lane configuration runs that same unexplained path, so more
+        # than one lane is refused while library GEMMs are in the step; with the
+        # hand-written GEMM kernels (no workgroup of which ever waits for another)
+        # two lanes are allowed again.
         want = max(LANES, cfg.gpt2_lanes)
-        if want > 2:
-            raise DeviceError("more than two GPT-2 lanes hung the GPU queue; use 1 or 2")
+        self.native_gemm = gemm_ops.enabled(self.device)
+        if want > 2 or (want > 1 and not self.native_gemm):
+            raise DeviceError(
+                "GPT-2 lanes > 1 are refused: concurrent steps on library GEMM kernels hung "
+                "the GPU queue and the cause is open (two lanes need the native GEMM path)"
+            )
         lanes = 1
-        rows = cfg.batch_size * cfg.seq_len
-        profiled = (model_cfg.n_embd, model_cfg.vocab_size, rows) == (768, 50257, 4096)
         full_batches = all(sz % cfg.batch_size == 0 for sz in shards.sizes)
-        if (cfg.client_streams and self.device.type == "cuda" and G > 1 and profiled
-                and full_batches):
+        if cfg.client_streams and self.device.type == "cuda" and G > 1 and full_batches:
             lanes = min(G, max(want, 1))
         self.lanes = max(1, lanes)
-        self._lm_head_done = torch.cuda.Event() if self.lanes > 1 else None
         self._grads = [torch.zeros(n, dtype=BF16, device=self.device) for _ in range(self.lanes)]
         self._gvs = [_views(self.layout, g) for g in self._grads]
         self._streams = (
@@ -152,6 +157,32 @@ class GPT2NativeTrainer(GroupTrainer):
             self._bufs[key] = _Buffers(self.m, batch, seq, self.device)
         return self._bufs[key]
 
+    # -- linear layers ------------------------------------------------------
+    def _lin_fwd(self, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None,
+                 out: torch.Tensor, gelu_out: torch.Tensor | None = None) -> None:
+        """out = x w^T (+ bias); gelu_out = gelu(out) when given."""
+        if self.native_gemm:
+            gemm_ops.linear_fwd(x, w, bias, out, gelu_out)
+            return
+        if bias is not None:
+            torch.addmm(bias, x, w.t(), out=out)
+        else:
+            torch.mm(x, w.t(), out=out)
+        if gelu_out is not None:
+            nn_ops.gelu_fwd(out, gelu_out)
+
+    def _lin_dgrad(self, dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
+        if self.native_gemm:
+            gemm_ops.linear_dgrad(dy, w, out)
+        else:
+            torch.mm(dy, w, out=out)
+
+    def _lin_wgrad(self, dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> None:
+        if self.native_gemm:
+            gemm_ops.linear_wgrad(dy, x, out)
+        else:
+            torch.mm(dy.t(), x, out=out)
+
     # -- forward ------------------------------------------------------------
     def _forward(self, w: dict[str, torch.Tensor], tokens: torch.Tensor, b: _Buffers) -> None:
         """Fills the activation buffers and leaves d(logits) in ``b.logits``,
@@ -171,27 +202,19 @@ class GPT2NativeTrainer(GroupTrainer):
             else:
                 nn_ops.ln_fwd(b.x_mid[l - 1], w[p + "ln_1.weight"], w[p + "ln_1.bias"],
                               b.ln1[l], st1[0], st1[1], delta=delta, x_out=b.x[l])
-            torch.addmm(w[p + "attn.c_attn.bias"], b.ln1[l], w[p + "attn.c_attn.weight"].t(),
-                        out=b.qkv[l])
+            self._lin_fwd(b.ln1[l], w[p + "attn.c_attn.weight"], w[p + "attn.c_attn.bias"], b.qkv[l])
             attn_ops.causal_attention_fwd(b.qkv[l], b.att[l], b.lse[l], b.batch, b.seq, m.n_head)
-            torch.addmm(w[p + "attn.c_proj.bias"], b.att[l], w[p + "attn.c_proj.weight"].t(),
-                        out=b.tmp_c)
+            self._lin_fwd(b.att[l], w[p + "attn.c_proj.weight"], w[p + "attn.c_proj.bias"], b.tmp_c)
             nn_ops.ln_fwd(b.x[l], w[p + "ln_2.weight"], w[p + "ln_2.bias"], b.ln2[l],
                           st2[0], st2[1], delta=b.tmp_c, x_out=b.x_mid[l])
-            torch.addmm(w[p + "c_fc.bias"], b.ln2[l], w[p + "c_fc.weight"].t(), out=b.fc[l])
-            nn_ops.gelu_fwd(b.fc[l], b.act[l])
-            torch.addmm(w[p + "c_proj.bias"], b.act[l], w[p + "c_proj.weight"].t(), out=b.tmp_c)
+            self._lin_fwd(b.ln2[l], w[p + "c_fc.weight"], w[p + "c_fc.bias"], b.fc[l],
+                          gelu_out=b.act[l])
+            self._lin_fwd(b.act[l], w[p + "c_proj.weight"], w[p + "c_proj.bias"], b.tmp_c)
             delta = b.tmp_c
         stf = b.stats[2 * L]
         nn_ops.ln_fwd(b.x_mid[L - 1], w["ln_f.weight"], w["ln_f.bias"], b.lnf, stf[0], stf[1],
                       delta=delta, x_out=b.x[L])
-        if self._lm_head_done is None:
-            torch.mm(b.lnf, w["wte.weight"].t(), out=b.logits[:, :V])
-        else:  # never two of these at once, whatever the lane
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(self._lm_head_done)
-            torch.mm(b.lnf, w["wte.weight"].t(), out=b.logits[:, :V])
-            self._lm_head_done.record(cur)
+        self._lin_fwd(b.lnf, w["wte.weight"], None, b.logits[:, :V])
         nn_ops.cross_entropy_fwd_bwd(b.logits, tgt, V, 1.0 / b.R, b.loss_rows, b.correct_rows)
 
     # -- backward -----------------------------------------------------------
@@ -200,8 +223,8 @@ class GPT2NativeTrainer(GroupTrainer):
         m, L = self.m, self.m.n_layer
         V = m.vocab_size
         dlog = b.logits[:, :V]
-        torch.mm(dlog.t(), b.lnf, out=g["wte.weight"])  # LM head shares the embedding matrix
-        torch.mm(dlog, w["wte.weight"], out=b.dln)
+        self._lin_wgrad(dlog, b.lnf, g["wte.weight"])  # LM head shares the embedding matrix
+        self._lin_dgrad(dlog, w["wte.weight"], b.dln)
         stf = b.stats[2 * L]
         # every LayerNorm backward also sums its d(x) over the rows: that is the bias
         # gradient of the projection that wrote into the residual stream before it
@@ -211,22 +234,22 @@ class GPT2NativeTrainer(GroupTrainer):
             p = f"h.{l}."
             st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
             # MLP: x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
-            torch.mm(b.dres.t(), b.act[l], out=g[p + "c_proj.weight"])
-            torch.mm(b.dres, w[p + "c_proj.weight"], out=b.dact)
+            self._lin_wgrad(b.dres, b.act[l], g[p + "c_proj.weight"])
+            self._lin_dgrad(b.dres, w[p + "c_proj.weight"], b.dact)
             nn_ops.gelu_bwd_colsum(b.fc[l], b.dact, b.dact, g[p + "c_fc.bias"])
-            torch.mm(b.dact.t(), b.ln2[l], out=g[p + "c_fc.weight"])
-            torch.mm(b.dact, w[p + "c_fc.weight"], out=b.dln)
+            self._lin_wgrad(b.dact, b.ln2[l], g[p + "c_fc.weight"])
+            self._lin_dgrad(b.dact, w[p + "c_fc.weight"], b.dln)
             nn_ops.ln_bwd(b.dln, b.x_mid[l], w[p + "ln_2.weight"], st2[0], st2[1], b.dres,
                           g[p + "ln_2.weight"], g[p + "ln_2.bias"], dres=b.dres,
                           dxsum=g[p + "attn.c_proj.bias"])
             # attention: x_mid = x + c_proj(attn(c_attn(ln_1(x))))
-            torch.mm(b.dres.t(), b.att[l], out=g[p + "attn.c_proj.weight"])
-            torch.mm(b.dres, w[p + "attn.c_proj.weight"], out=b.datt)
+            self._lin_wgrad(b.dres, b.att[l], g[p + "attn.c_proj.weight"])
+            self._lin_dgrad(b.dres, w[p + "attn.c_proj.weight"], b.datt)
             attn_ops.causal_attention_bwd(b.qkv[l], b.att[l], b.lse[l], b.datt, b.dqkv,
                                           b.attn_scratch, b.batch, b.seq, m.n_head)
             nn_ops.colsum(b.dqkv, g[p + "attn.c_attn.bias"])
-            torch.mm(b.dqkv.t(), b.ln1[l], out=g[p + "attn.c_attn.weight"])
-            torch.mm(b.dqkv, w[p + "attn.c_attn.weight"], out=b.dln)
+            self._lin_wgrad(b.dqkv, b.ln1[l], g[p + "attn.c_attn.weight"])
+            self._lin_dgrad(b.dqkv, w[p + "attn.c_attn.weight"], b.dln)
             nn_ops.ln_bwd(b.dln, b.x[l], w[p + "ln_1.weight"], st1[0], st1[1], b.dres,
                           g[p + "ln_1.weight"], g[p + "ln_1.bias"], dres=b.dres,
                           dxsum=g[f"h.{l - 1}.c_proj.bias"] if l > 0 else None)

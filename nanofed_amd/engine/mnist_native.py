@@ -226,7 +226,7 @@ class NativeBuffers:
         self.c2b_part = z(G, 72, 64, name="c2b_part")
         self.head_part = z(G, B // 8, 1440, name="head_part")
         self.metrics = z(G, 4, name="metrics")
-        self.eval_out = z(2)
+        self.eval_out = z(G, B // 8, 2)
         self.step_counter = z(G, dtype=torch.int64, name="step_counter")
         self.grad = grad if grad is not None else z(1, layout.trainable_numel)
         self.arena = arena
@@ -381,6 +381,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
                 self._groups.append(grp)
                 first += gs
             # (the streams are created at the first epoch, see _run_epoch)
+        self.stream_report: dict = {}
         self._graphs: list[list[torch.cuda.CUDAGraph]] | None = None
         self._chunks: list[tuple[int, int]] = []
         self._stream_trials: list[tuple[float, list[torch.cuda.Stream]]] = []
@@ -523,7 +524,24 @@ class MnistCnnNativeTrainer(GroupTrainer):
             t1.synchronize()
             self._stream_trials.append((t0.elapsed_time(t1), streams))
             if len(self._stream_trials) == self.STREAM_TRIALS:
-                self._group_streams = min(self._stream_trials, key=lambda t: t[0])[1]
+                best = min(range(self.STREAM_TRIALS), key=lambda i: self._stream_trials[i][0])
+                self._group_streams = self._stream_trials[best][1]
+                # what was tried and what was kept goes into the round report; the
+                # sets that lost are handed back to the runtime
+                self.stream_report = {
+                    "trial_epoch_ms": [round(t, 3) for t, _ in self._stream_trials],
+                    "chosen_trial": best,
+                    "groups": len(self._groups),
+                    "streams": len(self._group_streams),
+                }
+                from nanofed_amd.utils.streams import destroy_streams
+
+                torch.cuda.synchronize(self.device)
+                for i, (_, losers) in enumerate(self._stream_trials):
+                    if i != best:
+                        destroy_streams(losers)
+                self._stream_trials = [(t, []) if i != best else (t, st)
+                                       for i, (t, st) in enumerate(self._stream_trials)]
 
     def train_round(self, round_idx: int) -> torch.Tensor:
         cfg = self.cfg
@@ -584,13 +602,19 @@ class MnistCnnNativeTrainer(GroupTrainer):
             ev.nvalid.copy_(nvalid)
             ev.ctx.ragged = int(bool((nvalid == 0).any()))
             self._eval = ev
+            self._eval_active = (nvalid > 0).t().reshape(steps, GE, 1, 1).to(
+                device=self.device, dtype=torch.float64)
         ev = self._eval
         if ev.arena.data_ptr() != flat.data_ptr():
             ev.arena = flat
             ev.ctx.arena = flat.data_ptr()
-        ev.eval_out.zero_()
         ev.pack()
+        # every workgroup leaves its loss sum / hit count of the step in its own slot;
+        # the slots of the clients that had a batch are added here in fp64, in a
+        # fixed order, so the result does not depend on timing
+        total = torch.zeros(2, dtype=torch.float64, device=self.device)
         for s in range(steps):
             ev.eval_step(s * B, s)
-        loss_sum, correct = ev.eval_out.tolist()
+            total += (ev.eval_out.double() * self._eval_active[s]).sum(dim=(0, 1))
+        loss_sum, correct = total.tolist()
         return {"loss": loss_sum / n, "accuracy": correct / n, "samples": float(n)}

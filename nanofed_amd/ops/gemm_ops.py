@@ -1,0 +1,185 @@
+"""bf16 GEMMs on MFMA (csrc/hip/gemm_ops.hip) for the linear layers of the
+transformer trainer (the reference's only linear layers are ``nn.Linear`` in
+nanofed/models/mnist.py:24,27; its training step is nanofed/trainer/base.py:141-159).
+
+Three operand layouts cover a linear layer's forward, data gradient and weight
+gradient without any transposed copy:
+
+``linear_fwd``    y[M, N]  = x[M, K] @ w[N, K]^T (+ bias) (+ GELU)      "NT"
+``linear_dgrad``  dx[M, K] = dy[M, N] @ w[N, K]                         "NN"
+``linear_wgrad``  dw[N, K] = dy[M, N]^T @ x[M, K]                        "TN"
+
+Operands and results are bf16, accumulation is fp32.  CPU tensors (and GPUs
+without the library, which cannot happen on a built tree) run the same
+arithmetic through ``torch.mm`` in fp32 - that is also the oracle of the kernel
+tests.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import library
+
+
+def enabled(device: torch.device | None = None) -> bool:
+    """True when GEMMs of ``device`` tensors run on the hand-written kernels
+    (``NANOFED_NATIVE_GEMM=0`` routes them to the vendor library instead, for A/B
+    measurements)."""
+    if device is not None and torch.device(device).type != "cuda":
+        return False
+    if os.environ.get("NANOFED_NATIVE_GEMM", "1") == "0":
+        return False
+    try:
+        return hasattr(library.hip_lib(), "nf_gemm_bf16")
+    except Exception:  # noqa: BLE001 - no library: nothing native is enabled
+        return False
+
+
+_slabs: dict[tuple[int, int], torch.Tensor] = {}
+
+NT, NN, TN = 0, 1, 2  # operand layouts (see csrc/hip/gemm_ops.hip)
+
+
+def _check(t: torch.Tensor, name: str) -> None:
+    from nanofed_amd.core.exceptions import DeviceError
+
+    if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
+        raise DeviceError(f"gemm {name}: a bf16 matrix with unit column stride is required")
+    if t.stride(0) % 8 or t.data_ptr() % 16:
+        raise DeviceError(f"gemm {name}: row stride must be a multiple of 8 elements, base 16-byte aligned")
+
+
+def _slab_buffer(dev: torch.device, floats: int) -> torch.Tensor:
+    key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _slabs.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(floats, dtype=torch.float32, device=dev)
+        _slabs[key] = buf
+    return buf
+
+
+GEO_128, GEO_256x128, GEO_256 = 0, 1, 2
+_GEO_TILE = {GEO_128: (128, 128), GEO_256x128: (256, 128), GEO_256: (256, 256)}
+# NANOFED_GEMM_GEO=0|1|2 pins the workgroup tile (measurements)
+_FORCED_GEO = os.environ.get("NANOFED_GEMM_GEO")
+
+
+def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0) -> int:
+    """Workgroup tile for an ``M x N`` output with reduction length ``K``.  Bigger
+    tiles load fewer operand bytes per MFMA but make fewer workgroups and need a
+    long K loop to pay for their prologue.  The thresholds are read off
+    ``tools/bench_gemm.py --geometries`` at the GPT-2-small shapes: operands that
+    are read through the transposing LDS loads (dgrad, wgrad) gain more from large
+    tiles than the forward layout does."""
+    if _FORCED_GEO is not None:
+        return int(_FORCED_GEO)
+    ksteps = (K + 63) // 64
+    t256 = (-(-M // 256)) * (-(-N // 256))
+    t256x128 = (-(-M // 256)) * (-(-N // 128))
+    if layout == NT:
+        return GEO_256x128 if t256x128 >= 384 else GEO_128
+    if t256 >= 36 and ksteps >= 48:
+        return GEO_256
+    if t256x128 >= 48 and ksteps >= 24:
+        return GEO_256x128
+    return GEO_128
+
+
+def _launch(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int,
+            K: int, bias: torch.Tensor | None = None, out2: torch.Tensor | None = None,
+            splits: int | None = None, geo: int | None = None) -> None:
+    from ctypes import c_int, c_long, c_void_p
+
+    from nanofed_amd.core.exceptions import DeviceError
+
+    for t, name in ((a, "A"), (b, "B"), (out, "C")):
+        _check(t, name)
+    if out2 is not None:
+        _check(out2, "C2")
+        if out2.stride(0) != out.stride(0) or out2.shape != out.shape:
+            raise DeviceError("gemm: the second output must have the shape and stride of the first")
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.numel() != N
+                             or not bias.is_contiguous()):
+        raise DeviceError("gemm: bias must be a contiguous bf16 vector of N entries")
+    if tuple(out.shape) != (M, N):
+        raise DeviceError(f"gemm: output is {tuple(out.shape)}, expected {(M, N)}")
+    lib = library.hip_lib()
+    fn = lib.nf_gemm_bf16
+    if not getattr(fn, "_declared", False):
+        fn.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_void_p]
+        fn.restype = c_int
+        fn._declared = True
+    if geo is None:
+        geo = choose_geometry(M, N, K, layout)
+    if splits is None:
+        splits = choose_splits(M, N, K, geo)
+    slabs = _slab_buffer(out.device, splits * M * N) if splits > 1 else None
+    library.check(
+        fn(layout, geo, a.data_ptr(), b.data_ptr(), out.data_ptr(),
+           out2.data_ptr() if out2 is not None else None,
+           bias.data_ptr() if bias is not None else None,
+           slabs.data_ptr() if slabs is not None else None,
+           M, N, K, a.stride(0), b.stride(0), out.stride(0), splits,
+           library.stream_ptr(out.device)),
+        "nf_gemm_bf16",
+    )
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, out: torch.Tensor,
+               gelu_out: torch.Tensor | None = None) -> None:
+    """``out = x @ w.T (+ bias)``; with ``gelu_out`` also ``gelu_out = gelu(out)``
+    (tanh form, applied to the bf16-rounded ``out``).  x ``[M, K]``, w ``[N, K]``."""
+    M, K = x.shape
+    N = w.shape[0]
+    if x.device.type == "cuda" and enabled(x.device):
+        _launch(NT, x, w, out, M, N, K, bias=bias, out2=gelu_out)
+        return
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    out.copy_(y.to(torch.bfloat16))
+    if gelu_out is not None:
+        gelu_out.copy_(torch.nn.functional.gelu(out.float(), approximate="tanh").to(torch.bfloat16))
+
+
+def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
+    """``out = dy @ w``: dy ``[M, N]``, w ``[N, K]`` (as stored), out ``[M, K]``."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if dy.device.type == "cuda" and enabled(dy.device):
+        _launch(NN, dy, w, out, M, K, N)
+        return
+    out.copy_((dy.float() @ w.float()).to(torch.bfloat16))
+
+
+def choose_splits(M: int, N: int, K: int, geo: int = GEO_128) -> int:
+    """Split factor of a GEMM with ``M x N`` outputs and reduction length ``K``.  A
+    launch with fewer tiles than the chip has compute units is cut along K until the
+    tiles times ranges fill it, provided every range keeps at least 16 K steps of 64
+    (the fp32 slab round trip costs about as much as 10 steps)."""
+    bm, bn = _GEO_TILE[geo]
+    tiles = (-(-M // bm)) * (-(-N // bn))
+    if tiles >= 200:
+        return 1
+    ksteps = (K + 63) // 64
+    want = -(-256 // tiles)
+    return max(1, min(want, 16, ksteps // 16))
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> None:
+    """``out = dy.T @ x``: dy ``[R, N]``, x ``[R, K]``, out ``[N, K]`` - the
+    reduction runs over the rows, both operands are read as they are stored."""
+    R, N = dy.shape
+    K = x.shape[1]
+    if dy.device.type == "cuda" and enabled(dy.device):
+        _launch(TN, dy, x, out, N, K, R)
+        return
+    out.copy_((dy.float().t() @ x.float()).to(torch.bfloat16))
+
+
+def symbols() -> list[str]:
+    return ["nf_gemm_bf16", "nf_gemm_geometries"]

@@ -7,7 +7,8 @@ creation order, so consecutive pool streams of one priority can end up sharing
 hardware queues - their work then runs one chain after the other although it sits
 on different streams.  ``make_streams(n)`` creates ``n`` default-priority streams
 back to back with the runtime itself, which spreads them over the hardware queues,
-and wraps them for PyTorch.
+and wraps them for PyTorch; ``destroy_streams`` gives back the ones a caller no
+longer needs (the trainer tries several sets and keeps one).
 """
 
 from __future__ import annotations
@@ -17,7 +18,7 @@ import ctypes
 import torch
 
 _HIP_STREAM_NON_BLOCKING = 0x01
-_keep_alive: list[int] = []
+_owned: set[int] = set()  # handles created here and not yet destroyed
 
 
 def _runtime() -> ctypes.CDLL:
@@ -53,6 +54,27 @@ def make_streams(n: int, device: torch.device | int | None = None) -> list[torch
             if create(ctypes.byref(handle), _HIP_STREAM_NON_BLOCKING) != 0 or not handle.value:
                 out.append(torch.cuda.Stream(dev))
                 continue
-            _keep_alive.append(handle.value)  # lives as long as the process
+            _owned.add(handle.value)
             out.append(torch.cuda.ExternalStream(handle.value, device=dev))
     return out
+
+
+def destroy_streams(streams: list[torch.cuda.Stream]) -> int:
+    """Destroy streams that ``make_streams`` created (others are left alone: PyTorch
+    owns its pool).  The caller must have synchronised with them.  Returns how many
+    were destroyed."""
+    try:
+        destroy = _runtime().hipStreamDestroy
+        destroy.argtypes = [ctypes.c_void_p]
+        destroy.restype = ctypes.c_int
+    except (OSError, AttributeError):
+        return 0
+    done = 0
+    for st in streams:
+        handle = int(st.cuda_stream)
+        if handle in _owned:
+            st.synchronize()
+            if destroy(ctypes.c_void_p(handle)) == 0:
+                _owned.discard(handle)
+                done += 1
+    return done

@@ -52,3 +52,16 @@ def test_rounds_reduce_the_loss_and_evaluate():
     assert last.agg_metrics["loss"] < first.agg_metrics["loss"]
     ev = eng.evaluate()
     assert ev["samples"] == 2.0 and ev["loss"] > 0
+
+
+def test_more_than_one_lane_is_refused_without_the_native_gemm_path():
+    # concurrent client steps on vendor GEMM kernels hung the GPU queue once and the
+    # cause is open: the configuration must fail loudly instead of running that path
+    import pytest
+
+    from nanofed_amd.core.exceptions import DeviceError
+
+    with pytest.raises(DeviceError, match="lanes"):
+        _engine(gpt2_lanes=2)
+    with pytest.raises(DeviceError, match="lanes"):
+        _engine(gpt2_lanes=4)
