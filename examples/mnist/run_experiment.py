@@ -4,8 +4,9 @@
     python examples/mnist/run_experiment.py innode    # same client code, in-node transport (no sockets / JSON)
     python examples/mnist/run_experiment.py device    # the device engine: clients are arena rows on the GPU(s)
 
-The first two run anywhere (CPU or GPU); the third uses hand-written HIP
-kernels when a MI355X is present.  MNIST is read from ``./data/MNIST/raw`` if
+All three run anywhere (CPU or GPU).  On a MI355X the clients' ``train_epoch``
+calls of the first two modes and the rounds of the third run on the hand-written
+HIP kernels (``NANOFED_NATIVE_TRAINER=0`` keeps ``train_epoch`` on PyTorch ops).  MNIST is read from ``./data/MNIST/raw`` if
 the IDX files are there, otherwise a synthetic MNIST-shaped set is used.
 """
 
@@ -73,26 +74,31 @@ async def run_transport(kind: str) -> None:
         await server.stop()
 
 
-def run_device() -> None:
-    from nanofed_amd.engine import EngineConfig, FederatedEngine
+async def run_device() -> None:
+    """The coordinator's calls, served by the device engine: same configs, same
+    ``async for metrics in coordinator.start_training()``, same files under
+    ``base_dir``; the clients are arena rows that train on this process's GPU."""
+    from nanofed_amd import DeviceCoordinator
     from nanofed_amd.parallel import Communicator
 
     comm = Communicator.from_env()
-    engine = FederatedEngine(
-        EngineConfig(model="mnist_cnn", num_clients=len(CLIENTS), num_rounds=ROUNDS,
-                     local_epochs=LOCAL_EPOCHS, batch_size=64, learning_rate=LR,
-                     samples_per_client=list(CLIENTS.values()), dataset="mnist"),
-        comm=comm, base_dir=Path("runs/mnist_device"),
+    coordinator = DeviceCoordinator.create(
+        CoordinatorConfig(num_rounds=ROUNDS, min_clients=len(CLIENTS), min_completion_rate=1.0,
+                          round_timeout=600, base_dir=Path("runs/mnist_device")),
+        TrainingConfig(epochs=LOCAL_EPOCHS, batch_size=64, learning_rate=LR),
+        comm=comm, model="mnist_cnn", dataset="mnist", samples_per_client=list(CLIENTS.values()),
     )
-    for report in engine.run():
-        print(f"round {report.round_id}: {report.status} {report.agg_metrics} in {report.wall_s:.3f}s")
-    print("held-out:", engine.evaluate())
+    async for metrics in coordinator.start_training():
+        print(f"round {metrics.round_id}: {metrics.status.name} {metrics.agg_metrics}")
+    print("global metrics:", coordinator.training_progress["global_metrics"])
+    print("held-out:", coordinator.engine.evaluate())
+    coordinator.close()
     comm.close()
 
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "device"
     if mode == "device":
-        run_device()
+        asyncio.run(run_device())
     else:
         asyncio.run(run_transport(mode))

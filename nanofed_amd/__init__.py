@@ -6,7 +6,12 @@ device-plane additions live in ``nanofed_amd.engine``, ``nanofed_amd.ops``,
 """
 
 from nanofed_amd.communication import HTTPClient, HTTPServer
-from nanofed_amd.orchestration import Coordinator, CoordinatorConfig, coordinate
+from nanofed_amd.orchestration import (
+    Coordinator,
+    CoordinatorConfig,
+    DeviceCoordinator,
+    coordinate,
+)
 from nanofed_amd.server import FedAvgAggregator, ModelManager
 from nanofed_amd.trainer import PrivateTrainer, TorchTrainer, TrainingConfig
 
@@ -20,6 +25,7 @@ __all__ = [
     "PrivateTrainer",
     "Coordinator",
     "CoordinatorConfig",
+    "DeviceCoordinator",
     "FedAvgAggregator",
     "ModelManager",
     "coordinate",

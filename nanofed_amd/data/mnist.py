@@ -105,6 +105,20 @@ def normalize_mnist(images_u8: torch.Tensor) -> torch.Tensor:
     return (images_u8.float() / 255.0 - MNIST_MEAN) / MNIST_STD
 
 
+class MNISTTensorDataset(TensorDataset):
+    """``TensorDataset(normalised images, labels)`` that also keeps the raw uint8
+    images: a trainer that runs the hand-written kernels gathers batches from the
+    uint8 rows on the device and normalises inside its first kernel, so it needs
+    the bytes, not the floats the ``DataLoader`` would hand out."""
+
+    def __init__(self, images_u8: torch.Tensor, labels: torch.Tensor) -> None:
+        super().__init__(normalize_mnist(images_u8), labels)
+        self.images_u8 = images_u8
+        self.labels_i64 = labels
+        self.mean = MNIST_MEAN
+        self.std = MNIST_STD
+
+
 def load_mnist_data(
     data_dir: str | Path,
     batch_size: int,
@@ -118,9 +132,7 @@ def load_mnist_data(
         data_dir, train=train, download=download,
         synthetic_fallback=synthetic_fallback,
     )
-    dataset: TensorDataset | Subset = TensorDataset(
-        normalize_mnist(images), labels
-    )
+    dataset: TensorDataset | Subset = MNISTTensorDataset(images, labels)
     if subset_fraction < 1.0:
         n = int(len(dataset) * subset_fraction)
         rng = np.random.default_rng(seed)

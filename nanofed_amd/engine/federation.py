@@ -221,6 +221,9 @@ class _Persister:
     def close(self) -> None:
         self._jobs.join()
         self._jobs.put(None)
+        # a daemon thread that is still winding down when the interpreter exits can
+        # abort the process
+        self._thread.join(timeout=10.0)
 
 
 class FederatedEngine:

@@ -1,0 +1,147 @@
+"""Route of the reference-style training call to the hand-written kernels.
+
+A client written against the reference (examples/mnist/run_experiment.py:21-86
+there) builds a model, a ``DataLoader`` and an optimizer and calls
+``TorchTrainer.train_epoch(model, dataloader, optimizer, epoch)``
+(nanofed/trainer/base.py:115-198).  When that call describes exactly what the
+native MNIST step implements - an ``MNISTModel`` on a HIP device, batches of 64
+drawn at random from an MNIST-shaped uint8 set, plain SGD, no per-batch callbacks -
+the epoch runs on ``nanofed_amd.engine.mnist_native`` instead of PyTorch ops: the
+model's weights are copied into a one-client arena, the epoch is one hipGraph
+replay, and the trained weights are copied back into the module.  Anything else
+takes the PyTorch path unchanged.
+
+``NANOFED_NATIVE_TRAINER=0`` switches the route off.
+"""
+
+from __future__ import annotations
+
+import os
+import threading
+from typing import Any
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, RandomSampler, Subset
+
+from nanofed_amd.utils import Logger
+
+from .base import TrainingMetrics
+
+NATIVE_BATCH = 64
+# Client coroutines often run ``train_epoch`` in worker threads
+# (``asyncio.to_thread``).  Native sessions take turns: a hipGraph capture must not
+# see another thread's allocations, and the kernels of one epoch already fill the
+# chip's launch queue.
+_NATIVE_LOCK = threading.Lock()
+
+
+def _raw_dataset(dataset: Any) -> tuple[Any, np.ndarray] | None:
+    """``(dataset with .images_u8 / .labels_i64, row indices)`` or None."""
+    if isinstance(dataset, Subset):
+        inner = _raw_dataset(dataset.dataset)
+        if inner is None:
+            return None
+        base, rows = inner
+        return base, rows[np.asarray(dataset.indices, dtype=np.int64)]
+    if hasattr(dataset, "images_u8") and hasattr(dataset, "labels_i64"):
+        return dataset, np.arange(len(dataset), dtype=np.int64)
+    return None
+
+
+def native_epoch_supported(trainer: Any, model: Any, dataloader: Any, optimizer: Any) -> bool:
+    """True when ``train_epoch(model, dataloader, optimizer, ...)`` is the step the
+    native MNIST kernels implement."""
+    from nanofed_amd.models import MNISTModel
+
+    if os.environ.get("NANOFED_NATIVE_TRAINER", "1") == "0":
+        return False
+    cfg = trainer._config
+    if torch.device(cfg.device).type != "cuda" or not torch.cuda.is_available():
+        return False
+    if type(model) is not MNISTModel or cfg.max_batches is not None or trainer._callbacks:
+        return False
+    if not isinstance(dataloader, DataLoader) or dataloader.batch_size != NATIVE_BATCH:
+        return False
+    if dataloader.drop_last or not isinstance(dataloader.sampler, RandomSampler):
+        return False
+    raw = _raw_dataset(dataloader.dataset)
+    if raw is None or tuple(raw[0].images_u8.shape[1:]) != (1, 28, 28):
+        return False
+    if type(optimizer) is not torch.optim.SGD or len(optimizer.param_groups) != 1:
+        return False
+    group = optimizer.param_groups[0]
+    if group.get("momentum", 0) or group.get("nesterov", False) or group.get("dampening", 0):
+        return False
+    if group.get("maximize", False):
+        return False
+    own = {id(p) for p in model.parameters()}
+    return {id(p) for p in group["params"]} == own
+
+
+class NativeEpochSession:
+    """One client's native training state behind ``train_epoch``: a one-row arena
+    pool, the device-resident shard and the kernel trainer with its epoch graph."""
+
+    def __init__(self, dataloader: DataLoader, device: torch.device, lr: float, wd: float,
+                 seed: int = 0) -> None:
+        from nanofed_amd.engine.config import EngineConfig
+        from nanofed_amd.engine.data import DeviceShards, FederatedData
+        from nanofed_amd.engine.mnist_native import MnistCnnNativeTrainer, make_layout
+        from nanofed_amd.models import MNISTModel
+        from nanofed_amd.runtime.arena import ArenaPool
+
+        base, rows = _raw_dataset(dataloader.dataset)
+        images = base.images_u8[torch.from_numpy(rows)].contiguous()
+        labels = base.labels_i64[torch.from_numpy(rows)].contiguous()
+        n = len(rows)
+        self.samples = n
+        self.lr, self.wd = float(lr), float(wd)
+        self.device = device
+        cfg = EngineConfig(
+            model="mnist_cnn", num_clients=1, samples_per_client=n, batch_size=NATIVE_BATCH,
+            local_epochs=1, learning_rate=self.lr, weight_decay=self.wd, dtype="bf16",
+            backend="native", seed=seed, eval_samples=0,
+        )
+        data = FederatedData("image", images, labels, [np.arange(n)], None, None,
+                             (float(base.mean),), (float(base.std),))
+        self.layout = make_layout(MNISTModel())
+        self.pool = ArenaPool(self.layout, 1, device)
+        self.shards = DeviceShards(data, [0], device, NATIVE_BATCH, seed)
+        self.trainer = MnistCnnNativeTrainer(cfg, self.pool, self.shards, data)
+        self.steps = self.shards.steps_per_epoch(0)
+        self.epochs_run = 0
+
+    @torch.no_grad()
+    def train_epoch(self, model: torch.nn.Module, epoch: int) -> TrainingMetrics:
+        from nanofed_amd.engine.trainers import M_ACC, M_LOSS
+
+        with _NATIVE_LOCK:
+            arena = self.pool[0]
+            arena.load_state_dict(model.state_dict())
+            metrics = self.trainer.train_round(self.epochs_run)  # one local epoch
+            self.epochs_run += 1
+            model.load_state_dict(arena.state_dict(self.device))
+            loss, acc = metrics[0, M_LOSS].item(), metrics[0, M_ACC].item()
+        return TrainingMetrics(loss=float(loss), accuracy=float(acc), epoch=epoch,
+                               batch=max(self.steps - 1, 0), samples_processed=self.samples)
+
+
+def native_session_for(trainer: Any, dataloader: DataLoader, optimizer: Any) -> NativeEpochSession:
+    """The session of ``dataloader`` (built once: it places the shard in HBM and
+    captures the epoch graph); a new learning rate or weight decay builds a new one,
+    because they are arguments of the captured kernels."""
+    group = optimizer.param_groups[0]
+    lr, wd = float(group["lr"]), float(group.get("weight_decay", 0.0))
+    cache = trainer.__dict__.setdefault("_native_sessions", {})
+    key = id(dataloader)
+    session = cache.get(key)
+    if session is None or session.lr != lr or session.wd != wd:
+        Logger().info(
+            f"train_epoch runs on the native MNIST kernels ({len(dataloader.dataset)} samples, "
+            f"lr {lr}, one hipGraph per epoch)"
+        )
+        with _NATIVE_LOCK:
+            session = NativeEpochSession(dataloader, torch.device(trainer._config.device), lr, wd)
+        cache[key] = session
+    return session

@@ -352,9 +352,8 @@ def test_idle_clients_are_skipped_without_changing_the_result():
         outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reps], ev))
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
-    # the evaluation sums batches with float atomics: equal up to the summation order
-    assert outs[0][2]["accuracy"] == outs[1][2]["accuracy"]
-    assert outs[0][2]["loss"] == pytest.approx(outs[1][2]["loss"], rel=1e-5)
+    # the evaluation adds per-workgroup sums in a fixed order: identical, not close
+    assert outs[0][2] == outs[1][2]
 
 
 def test_client_groups_train_the_same_model(monkeypatch):
