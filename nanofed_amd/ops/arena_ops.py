@@ -432,6 +432,10 @@ def screen_rows(
         return records
     if rows.dtype != torch.float32 or rows.stride(1) != 1 or rows.data_ptr() % 16:
         raise DeviceError("screen_rows: rows must be float32, unit inner stride, 16-byte aligned")
+    # the kernel reads float4 pieces: every row must start on a 16-byte boundary
+    row_stride = rows.stride(0) if G > 1 else (n + 3) & ~3
+    if row_stride % 4:
+        raise DeviceError("screen_rows: the row stride must be a multiple of 4 floats")
     library.require_flat_f32(records, "screen_rows records", align=4)
     if ref is not None:
         library.require_flat_f32(ref, "screen_rows reference")
@@ -445,7 +449,7 @@ def screen_rows(
         _screen_ws[key] = ws
     library.check(
         lib.nf_screen_rows(
-            _ptr(rows), c_int(G), c_long(rows.stride(0)), c_long(n),
+            _ptr(rows), c_int(G), c_long(row_stride), c_long(n),
             _ptr(ref) if ref is not None else c_void_p(0), _ptr(ws), _ptr(records),
             c_int(records.stride(0)), c_int(col_sq), c_int(col_valid), c_float(max_sq),
             library.stream_ptr(dev),

@@ -92,7 +92,7 @@ def test_one_epoch_equals_one_engine_round_of_one_client():
     engine = FederatedEngine(
         EngineConfig(model="mnist_cnn", num_clients=1, samples_per_client=n, local_epochs=1,
                      batch_size=64, learning_rate=0.05, eval_samples=0, backend="native"),
-        comm=Communicator(), data=data,
+        comm=Communicator(device=torch.device("cuda", 0)), data=data,
     )
     model = MNISTModel().to("cuda")
     model.load_state_dict(engine.global_arena.state_dict("cuda"))
@@ -113,7 +113,7 @@ def test_device_coordinator_rounds_on_the_native_trainer(tmp_path):
     kw = dict(model="mnist_cnn", samples_per_client=512, eval_samples=256)
     coordinator = DeviceCoordinator.create(
         config, TrainingConfig(epochs=2, batch_size=64, learning_rate=0.1),
-        comm=Communicator(), **kw,
+        comm=Communicator(device=torch.device("cuda", 0)), **kw,
     )
     assert coordinator.engine.backend == "native"
 
@@ -132,7 +132,7 @@ def test_device_coordinator_rounds_on_the_native_trainer(tmp_path):
     for k in saved:
         torch.testing.assert_close(saved[k], live[k], rtol=0, atol=0)
     # the same engine without the coordinator: identical model
-    plain = FederatedEngine(coordinator.engine.cfg, comm=Communicator())
+    plain = FederatedEngine(coordinator.engine.cfg, comm=Communicator(device=torch.device("cuda", 0)))
     plain.run(2)
     torch.testing.assert_close(plain.global_arena.data, coordinator.engine.global_arena.data,
                                rtol=0, atol=0)

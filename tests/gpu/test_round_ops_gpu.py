@@ -16,7 +16,8 @@ DEV = "cuda"
 @pytest.mark.parametrize("G,n", [(1, 37), (8, 1199882), (5, 65537)])
 def test_screen_rows_matches_the_cpu_oracle(G, n):
     torch.manual_seed(G * 1000 + n % 97)
-    rows = torch.randn(G, n)
+    pitch = (n + 3) // 4 * 4  # rows of a pool start on 16-byte boundaries
+    rows = torch.randn(G, pitch)[:, :n]
     if G > 2:
         rows[2, n // 2] = float("inf")
         rows[1] *= 40.0
@@ -26,22 +27,33 @@ def test_screen_rows_matches_the_cpu_oracle(G, n):
     want = rec.clone()
     bound = 20.0 * (n ** 0.5)
     ops.screen_rows(rows, want[:G], col_sq=4, col_valid=3, ref=ref, max_norm=bound)
+    dev_rows = torch.zeros(G, pitch, device=DEV)
+    dev_rows[:, :n] = rows.to(DEV)
+    dev_rows = dev_rows[:, :n]
     got = rec.to(DEV)
-    ops.screen_rows(rows.to(DEV), got[:G], col_sq=4, col_valid=3, ref=ref.to(DEV), max_norm=bound)
+    ops.screen_rows(dev_rows, got[:G], col_sq=4, col_valid=3, ref=ref.to(DEV), max_norm=bound)
     torch.testing.assert_close(got.cpu()[:, 4], want[:, 4], rtol=2e-5, atol=1e-3)
     assert got.cpu()[:, 3].tolist() == want[:, 3].tolist()
     assert got.cpu()[G].abs().sum() == 0  # the row after the last one is not touched
     # without a reference: finite check of the rows themselves
     got2 = rec.to(DEV)
-    ops.screen_rows(rows.to(DEV), got2[:G], col_sq=4, col_valid=3)
+    ops.screen_rows(dev_rows, got2[:G], col_sq=4, col_valid=3)
     want2 = rec.clone()
     ops.screen_rows(rows, want2[:G], col_sq=4, col_valid=3)
     assert got2.cpu()[:, 3].tolist() == want2[:, 3].tolist()
 
 
+def test_screen_rows_refuses_rows_that_are_not_16_byte_aligned():
+    from nanofed_amd.core.exceptions import DeviceError
+
+    rows = torch.randn(3, 1001, device=DEV)
+    with pytest.raises(DeviceError):
+        ops.screen_rows(rows, torch.zeros(3, 8, device=DEV), 4, 3)
+
+
 def test_screen_rows_is_run_to_run_identical():
     torch.manual_seed(3)
-    rows = torch.randn(8, 300001, device=DEV)
+    rows = torch.randn(8, 300004, device=DEV)[:, :300001]
     ref = torch.randn(300001, device=DEV)
     outs = []
     for _ in range(3):
@@ -119,8 +131,8 @@ def test_tail_graph_replays_equal_eager_tails_round_after_round():
     """Six rounds with the captured tail against six with the eager tail.  Between
     the replays the program does its own eager work (training graphs, the host
     read of the records, an evaluation), as a real run does."""
-    graph = FederatedEngine(EngineConfig(tail_graph=True, **CFG), comm=Communicator())
-    eager = FederatedEngine(EngineConfig(tail_graph=False, **CFG), comm=Communicator())
+    graph = FederatedEngine(EngineConfig(tail_graph=True, **CFG), comm=Communicator(device=torch.device("cuda", 0)))
+    eager = FederatedEngine(EngineConfig(tail_graph=False, **CFG), comm=Communicator(device=torch.device("cuda", 0)))
     for r in range(6):
         a, b = graph.run_round(), eager.run_round()
         assert torch.equal(graph.global_arena.data, eager.global_arena.data), f"round {r}"
@@ -137,13 +149,18 @@ def test_tail_graph_replays_equal_eager_tails_round_after_round():
 
 def test_a_faulty_round_between_replays_runs_eagerly_and_the_graph_stays_valid():
     faults = dict(drop={3: {2}}, poison={4: {5}})
-    graph = FederatedEngine(EngineConfig(tail_graph=True, **CFG), comm=Communicator(),
+    graph = FederatedEngine(EngineConfig(tail_graph=True, **CFG), comm=Communicator(device=torch.device("cuda", 0)),
                             faults=FaultPlan(**faults))
-    eager = FederatedEngine(EngineConfig(tail_graph=False, **CFG), comm=Communicator(),
+    eager = FederatedEngine(EngineConfig(tail_graph=False, **CFG), comm=Communicator(device=torch.device("cuda", 0)),
                             faults=FaultPlan(**faults))
     for r in range(7):
         a, b = graph.run_round(), eager.run_round()
         assert torch.equal(graph.global_arena.data, eager.global_arena.data), f"round {r}"
-        assert a.num_clients == b.num_clients == (7 if r in (3, 4) else 8)
+        assert a.num_clients == b.num_clients
+        assert [c["valid"] for c in a.client_metrics] == [c["valid"] for c in b.client_metrics]
+        if r == 3:
+            assert not a.client_metrics[2]["valid"]
+        if r == 4:
+            assert not a.client_metrics[5]["valid"]
     graph.close()
     eager.close()
