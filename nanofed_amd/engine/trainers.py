@@ -33,6 +33,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from nanofed_amd import ops
+from nanofed_amd.core.exceptions import DeviceError
 from nanofed_amd.runtime.arena import ArenaPool
 
 from .config import EngineConfig
@@ -94,6 +95,30 @@ class TorchGroupTrainer(GroupTrainer):
         self._acc = torch.zeros(len(pool), 3, dtype=torch.float32, device=self.device)
         self._amp = cfg.dtype == "bf16" and self.device.type == "cuda"
         self._dp_step = 0
+        self._accountants = None
+        if cfg.dp is not None:
+            if cfg.dp.mode not in ("per_sample", "batch"):
+                raise DeviceError(f"unknown DPConfig.mode {cfg.dp.mode!r}")
+            if cfg.dp.mode == "per_sample" and any(
+                isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.modules[0].modules()
+            ):
+                raise DeviceError(
+                    "per-sample clipping needs independent examples; a model with BatchNorm "
+                    "takes DPConfig(mode='batch')"
+                )
+        if cfg.dp is not None and cfg.dp.noise_multiplier > 0:
+            # (without noise there is nothing to account for: clipping alone is not private)
+            from nanofed_amd.privacy import PrivacyConfig
+            from nanofed_amd.privacy.accountant.rdp import SubsampledRDPAccountant
+
+            pc = PrivacyConfig(
+                epsilon=min(max(cfg.dp.epsilon, 0.01), 10.0), delta=cfg.dp.delta,
+                max_gradient_norm=cfg.dp.max_gradient_norm,
+                noise_multiplier=cfg.dp.noise_multiplier,
+            )
+            self._accountants = [
+                SubsampledRDPAccountant(pc, dataset_size=max(n, 1)) for n in shards.sizes
+            ]
         # whole-step hipGraphs (forward + backward + SGD of one client): DP draws
         # its noise offset on the host, so it stays eager
         self._use_graph = (
@@ -240,12 +265,15 @@ class TorchGroupTrainer(GroupTrainer):
         x, y = self.shards.batch(rows)
         if self._channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self._amp):
-            out = module(x)
-            loss = classification_loss(out, y)
-        loss.backward()
-        if cfg.dp is not None:
-            self._privatise(k, int(rows.numel()))
+        if cfg.dp is not None and cfg.dp.mode == "per_sample":
+            loss, out = self._per_sample_step(k, x, y)
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self._amp):
+                out = module(x)
+                loss = classification_loss(out, y)
+            loss.backward()
+            if cfg.dp is not None:
+                self._privatise(k, int(rows.numel()))
         if self._direct:
             self._apply_gradients(k)
         else:
@@ -257,6 +285,49 @@ class TorchGroupTrainer(GroupTrainer):
         acc[0] += loss.detach()
         acc[1] += count_correct(out.detach(), y)
         acc[2] += 1.0
+
+    def _per_sample_step(self, k: int, x: torch.Tensor, y: torch.Tensor):
+        """DP-SGD gradient of one batch (Abadi et al.): every example's gradient is
+        clipped to ``max_gradient_norm``, the clipped gradients are averaged and
+        Gaussian noise of standard deviation ``noise_multiplier * max_gradient_norm
+        / batch`` is added.  The per-example gradients come from ``torch.func``
+        (vmap over grad of the functional model) - the portable counterpart of the
+        native trainer's per-sample kernels.  Leaves the result in the client's
+        flat gradient buffer; returns (mean loss, outputs)."""
+        from torch.func import functional_call, grad, vmap
+
+        dp = self.cfg.dp
+        module = self.modules[k]
+        arena = self.pool[k]
+        params = {n: p.detach() for n, p in module.named_parameters()}
+        buffers = {n: b for n, b in module.named_buffers()}
+
+        def loss_one(p, xi, yi):
+            out = functional_call(module, (p, buffers), (xi.unsqueeze(0),))
+            return classification_loss(out, yi.unsqueeze(0)), (out[0], )
+
+        grads, (outs,) = vmap(
+            grad(loss_one, has_aux=True), in_dims=(None, 0, 0), randomness="different"
+        )(params, x, y)
+        B = x.shape[0]
+        sq = torch.zeros(B, dtype=torch.float32, device=x.device)
+        for g in grads.values():
+            sq += g.reshape(B, -1).float().square().sum(dim=1)
+        factor = (dp.max_gradient_norm / sq.sqrt().clamp(min=1e-12)).clamp(max=1.0)
+        gviews = arena.grad_views()
+        for name, g in grads.items():
+            mean = (g.float() * factor.view(B, *([1] * (g.dim() - 1)))).sum(dim=0) / B
+            gviews[name].copy_(mean)
+        cid = self.shards.client_ids[k]
+        self._dp_step += 1
+        std = dp.noise_multiplier * dp.max_gradient_norm / B
+        if std > 0:
+            # clip bound far above any norm: this call only adds the noise
+            ops.clip_noise(arena.grad, 1e30, std, seed=self.cfg.seed * 2654435761 + cid,
+                           offset=self._dp_step, out=arena.grad)
+        with torch.no_grad():
+            loss = classification_loss(outs, y)
+        return loss, outs
 
     def _privatise(self, k: int, batch: int) -> None:
         """Batch-level clip + Gaussian noise on the gradient arena - the
@@ -272,14 +343,25 @@ class TorchGroupTrainer(GroupTrainer):
         )
 
     def train_round(self, round_idx: int) -> torch.Tensor:
-        if not self._autotune:
-            return self._train_round(round_idx)
-        previous = torch.backends.cudnn.benchmark
-        torch.backends.cudnn.benchmark = True
-        try:
-            return self._train_round(round_idx)
-        finally:
-            torch.backends.cudnn.benchmark = previous
+        # PyTorch's dropout draws from the process-wide generators.  The round runs
+        # on a fork of them, seeded from (run seed, round, first client), so that its
+        # randomness is a function of the round number - a repeated or resumed round,
+        # or a second engine in the same process, draws the same masks - and the
+        # caller's generators are left as they were.
+        devices = [self.device] if self.device.type == "cuda" else []
+        first = self.shards.client_ids[0] if self.shards.client_ids else 0
+        with torch.random.fork_rng(devices=devices):
+            torch.manual_seed(
+                (self.cfg.seed * 1000003 + round_idx * 7919 + first * 104729 + 17) & 0x7FFFFFFFFFFFFFFF
+            )
+            if not self._autotune:
+                return self._train_round(round_idx)
+            previous = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = True
+            try:
+                return self._train_round(round_idx)
+            finally:
+                torch.backends.cudnn.benchmark = previous
 
     def _train_round(self, round_idx: int) -> torch.Tensor:
         cfg = self.cfg
@@ -294,6 +376,12 @@ class TorchGroupTrainer(GroupTrainer):
             self._train_clients_concurrently(round_idx)
         else:
             for k in range(G):
+                # one client after the other: its dropout stream depends on its own
+                # id only, so the result does not depend on how clients map to ranks
+                cid = self.shards.client_ids[k]
+                torch.manual_seed(
+                    (cfg.seed * 1000003 + round_idx * 7919 + cid * 104729 + 17) & 0x7FFFFFFFFFFFFFFF
+                )
                 for epoch in range(cfg.local_epochs):
                     self._acc[k].zero_()
                     perm = self.shards.epoch_permutation(k, round_idx, epoch)
@@ -309,6 +397,16 @@ class TorchGroupTrainer(GroupTrainer):
             self.metrics[k, M_ACC] = self._acc[k, 1] / batches
             self.metrics[k, M_VALID] = 1.0
             self.pool[k].pull_int_buffers(self.modules[k])
+        if self._accountants is not None:
+            # privacy spent is a function of the number of noisy steps since round 0
+            eps = [
+                acc.epsilon_after(
+                    (round_idx + 1) * cfg.local_epochs * self.shards.steps_per_epoch(k),
+                    cfg.dp.noise_multiplier, cfg.batch_size,
+                )
+                for k, acc in enumerate(self._accountants)
+            ]
+            self.metrics[:, M_EPSILON] = torch.tensor(eps, dtype=torch.float32).to(self.device)
         return self.metrics
 
     def _train_clients_concurrently(self, round_idx: int) -> None:
