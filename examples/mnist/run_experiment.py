@@ -25,6 +25,7 @@ from nanofed_amd import (  # noqa: E402
     TorchTrainer, TrainingConfig, coordinate,
 )
 from nanofed_amd.communication import InNodeClient, InNodeServer  # noqa: E402
+from nanofed_amd.core.exceptions import NanoFedError  # noqa: E402
 from nanofed_amd.data import load_mnist_data  # noqa: E402
 from nanofed_amd.models import MNISTModel  # noqa: E402
 
@@ -40,7 +41,12 @@ async def run_client(make_client, client_id: str, num_samples: int, device: str)
     done: set[int] = set()
     async with make_client(client_id) as client:
         while not await client.check_server_status():
-            state, rnd = await client.fetch_global_model()
+            try:
+                state, rnd = await client.fetch_global_model()
+            except NanoFedError:
+                if await client.check_server_status():
+                    break  # the last round closed between the two calls
+                raise
             if rnd in done:
                 await asyncio.sleep(0.05)
                 continue

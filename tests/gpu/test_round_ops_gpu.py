@@ -164,3 +164,41 @@ def test_a_faulty_round_between_replays_runs_eagerly_and_the_graph_stays_valid()
             assert not a.client_metrics[5]["valid"]
     graph.close()
     eager.close()
+
+
+def _engine(faults=None, **kw):
+    cfg = dict(model="mnist_cnn", num_clients=8, samples_per_client=256, local_epochs=1,
+               eval_samples=128)
+    cfg.update(kw)
+    return FederatedEngine(EngineConfig(**cfg), comm=Communicator(device=torch.device("cuda", 0)),
+                           faults=FaultPlan(**(faults or {})))
+
+
+def test_a_fifty_fold_update_is_masked_out_by_the_z_score_screen():
+    eng = _engine(faults=dict(scale={0: {5: 50.0}}), zscore_threshold=2.0)
+    ref = _engine(faults=dict(drop={0: {5}}))
+    a, b = eng.run_round(), ref.run_round()
+    assert [c["valid"] for c in a.client_metrics] == [True] * 5 + [False] + [True] * 2
+    assert a.agg_metrics["anomalous_clients"] == 1.0 and a.num_clients == 7
+    norms = [c["update_norm"] for c in a.client_metrics]
+    assert norms[5] > 20 * max(norms[:5] + norms[6:])
+    # leaving the outlier out is the same as the client never reporting
+    torch.testing.assert_close(eng.global_arena.data, ref.global_arena.data, rtol=0, atol=0)
+    assert b.num_clients == 7
+    eng.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("drop", [None, {0: {2, 6}}])
+def test_a_pairwise_masked_round_equals_the_plain_round(drop):
+    faults = dict(drop=drop) if drop else {}
+    plain = _engine(faults=dict(faults))
+    blind = _engine(faults=dict(faults), secure_agg="pairwise")
+    a, b = plain.run_round(), blind.run_round()
+    assert a.num_clients == b.num_clients == (6 if drop else 8)
+    torch.testing.assert_close(blind.global_arena.data, plain.global_arena.data, rtol=0, atol=1e-5)
+    # what crosses the reduce is blinded: a masked row is far from the client's model
+    row = blind.pool[0].data
+    assert float((row - plain.pool[0].data * blind._shares_host[0]).abs().mean()) > 0.1
+    plain.close()
+    blind.close()
