@@ -1,4 +1,4 @@
-.PHONY: install build test test-gpu lint format format-check host-sanitize clean bench docs changelog release-prepare release
+.PHONY: install build test test-gpu lint typecheck notebook format format-check host-sanitize clean bench docs changelog release-prepare release
 
 install:
 	python -m pip install -e . --no-build-isolation --no-deps
@@ -13,8 +13,11 @@ test-gpu: build
 	python -u -m pytest tests -q -m gpu --timeout 120 --timeout-method thread
 
 lint:
-	python -m compileall -q nanofed_amd tests bench.py
-	@command -v ruff >/dev/null && ruff check nanofed_amd tests || echo "ruff not installed: syntax check only"
+	python -m compileall -q nanofed_amd scripts tests tools bench.py
+	@command -v ruff >/dev/null && ruff check nanofed_amd scripts tests tools bench.py || echo "ruff not installed: syntax check only"
+
+typecheck:
+	@python -c "import mypy" 2>/dev/null && python -m mypy nanofed_amd || echo "mypy not installed"
 
 format:
 	@command -v ruff >/dev/null && ruff format nanofed_amd tests || echo "ruff not installed"
@@ -35,13 +38,16 @@ clean:
 	find . -name __pycache__ -type d -prune -exec rm -rf {} +
 
 docs:
-	@command -v mkdocs >/dev/null && mkdocs build || echo "mkdocs not installed: the documentation sources are the Markdown files under docs/"
+	@python -c "import sphinx" 2>/dev/null && python -m sphinx -b html docs/source docs/_build/html || echo "sphinx not installed: the documentation sources are the reStructuredText files under docs/source"
+
+notebook:
+	python tools/execute_notebook.py examples/mnist/tutorial.ipynb
 
 changelog:
-	python scripts/changelog.py
+	python scripts/changelog.py $(VERSION)
 
 release-prepare:
 	python scripts/prepare_release.py $(VERSION)
 
 release:
-	bash scripts/release.sh $(VERSION)
+	bash scripts/release.sh
