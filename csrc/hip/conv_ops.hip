@@ -69,23 +69,12 @@ struct ConvGeo {
 // element offset of its first channel in the activation tensor, or -1 in the halo
 // outside the image.
 __device__ __forceinline__ int patch_source(const ConvGeo& g, int row0, int pp) {
-    const int PW = g.W + 2, PR = g.RI + 2;
-    const int band = pp / (PR * PW);
-    const int rem = pp - band * PR * PW;
-    const int pr = rem / PW, pc = rem - pr * PW;
-    const int grow = row0 + band * g.RI;
-    const int img = grow >> g.logH, y0 = grow & (g.H - 1);
-    const int yy = y0 + pr - 1, xx = pc - 1;
-    if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) return -1;
-    return ((img * g.H + yy) * g.W + xx) * g.Cin;
+    return nfix::conv_patch_source(g.H, g.W, g.logH, g.RI, g.Cin, row0, pp);
 }
 
 // Patch index (without tap shift) of pixel m of a tile.
 __device__ __forceinline__ int patch_index(const ConvGeo& g, int m) {
-    const int band = m >> (g.logRI + g.logW);
-    const int r = (m >> g.logW) & (g.RI - 1);
-    const int xx = m & (g.W - 1);
-    return (band * (g.RI + 2) + r) * (g.W + 2) + xx;
+    return nfix::conv_patch_index(g.W, g.logW, g.RI, g.logRI, m);
 }
 
 // kDgrad: the launch computes a data gradient.  x is then dY, y is dX, g.Cin / g.Cout are

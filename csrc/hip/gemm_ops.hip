@@ -97,13 +97,11 @@ __device__ __forceinline__ uint4 mask_tail(uint4 v, int valid) {
 }
 
 // byte offset of piece `chunk` (8 k) of row `row` in a k-contiguous tile (128-byte rows)
-__device__ __forceinline__ int kc_off(int row, int chunk) {
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
+__device__ __forceinline__ int kc_off(int row, int chunk) { return nfix::gemm_kc_off(row, chunk); }
 // byte offset of x byte position `xb` of k row `k` in a k-major tile with rows of ROWB bytes
 template <int ROWB>
 __device__ __forceinline__ int km_off(int k, int xb) {
-    return k * ROWB + ((((xb >> 6) ^ (k & 3)) << 6) | (xb & 63));
+    return nfix::gemm_km_off(ROWB, k, xb);
 }
 
 // MFMA fragment of a k-major tile: for lane l the 8 values tile[k0 + 8 (l >> 5) + j][x0 + (l & 31)]
@@ -132,11 +130,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ranges of tile indices, one per XCD (ids congruent mod 8), tiles numbered
 // column-fastest.
 __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int total = tiles_m * tiles_n;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = id & 7, slot = id >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int t = start + slot;
+    const int t = nfix::gemm_tile_index(id, tiles_m * tiles_n);
     tm = t / tiles_n;
     tn = t - tm * tiles_n;
 }

@@ -194,7 +194,7 @@ constexpr int kFwdLds = 64 * 592;  // filter staging (37888 B) > band image (260
 // window-major row order of the MFMA blocks every ds_read_b128 lane group then
 // touches 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int fwd_swz(int pixel, int col, int chunk) {
-    return pixel * 64 + ((chunk ^ ((col >> 1) & 3)) << 4);
+    return nfix::mnist_fwd_swz(pixel, col, chunk);
 }
 
 __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
@@ -700,7 +700,7 @@ struct PoolWindow {
     }
 };
 
-constexpr int kDgPatchRows = 13, kDgPatchCols = 28;
+constexpr int kDgPatchRows = nfix::kMnistDgPatchRows, kDgPatchCols = nfix::kMnistDgPatchCols;
 constexpr int kDgPatchBytes = kDgPatchRows * kDgPatchCols * 128;  // 46592
 constexpr int kDgPixPad = 704;                                    // 22 blocks of 32
 constexpr int kDgLds = kDgPatchBytes + 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10 * 4;
@@ -709,7 +709,7 @@ constexpr int kDgLds = kDgPatchBytes + 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10
 // ((pc >> 1) + 5 * pr) & 7: conflict-free for 32 linear pixels of a 26-wide
 // image shifted by any tap, including the row wrap inside a block.
 __device__ __forceinline__ int dg_swz(int pr, int pc, int part) {
-    return (pr * kDgPatchCols + pc) * 128 + ((part ^ (((pc >> 1) + 5 * pr) & 7)) << 4);
+    return nfix::mnist_dg_swz(pr, pc, part);
 }
 
 __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off, int bx, int g) {

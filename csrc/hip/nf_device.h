@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../common/index_math.h"
+
 namespace nfd {
 
 typedef __bf16 bf16;
@@ -23,9 +25,7 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ int acc_row(int reg, int lane) {
-    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-}
+__device__ __forceinline__ int acc_row(int reg, int lane) { return nfix::mfma32_acc_row(reg, lane); }
 
 // One 4x16 transposed LDS read: within each group of 16 lanes, lane 4q+p
 // supplies the address of row q, columns 4p..4p+3; lane i receives column i

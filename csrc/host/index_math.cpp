@@ -1,0 +1,20 @@
+// Host exports of the kernels' index arithmetic (csrc/common/index_math.h) for the
+// bounds / bijectivity tests.  Nothing here runs in production paths.
+#include "../common/index_math.h"
+
+extern "C" {
+
+int nf_ix_gemm_kc_off(int row, int chunk) { return nfix::gemm_kc_off(row, chunk); }
+int nf_ix_gemm_km_off(int rowb, int k, int xb) { return nfix::gemm_km_off(rowb, k, xb); }
+int nf_ix_gemm_tile_index(int id, int total) { return nfix::gemm_tile_index(id, total); }
+int nf_ix_mnist_fwd_swz(int pixel, int col, int chunk) { return nfix::mnist_fwd_swz(pixel, col, chunk); }
+int nf_ix_mnist_dg_swz(int pr, int pc, int part) { return nfix::mnist_dg_swz(pr, pc, part); }
+int nf_ix_mfma32_acc_row(int reg, int lane) { return nfix::mfma32_acc_row(reg, lane); }
+int nf_ix_conv_patch_source(int H, int W, int logH, int RI, int Cin, int row0, int pp) {
+    return nfix::conv_patch_source(H, W, logH, RI, Cin, row0, pp);
+}
+int nf_ix_conv_patch_index(int W, int logW, int RI, int logRI, int m) {
+    return nfix::conv_patch_index(W, logW, RI, logRI, m);
+}
+
+}  // extern "C"

@@ -55,6 +55,8 @@ def _hipcc() -> str:
 def _newest_header(src_dir: Path) -> float:
     stamps = [p.stat().st_mtime for p in src_dir.glob("*.h")]
     stamps += [p.stat().st_mtime for p in src_dir.glob("*.hpp")]
+    # headers shared by host and device code
+    stamps += [p.stat().st_mtime for p in (CSRC / "common").glob("*.h")]
     return max(stamps, default=0.0)
 
 

@@ -1,0 +1,112 @@
+"""Bounds, alignment and bijectivity of the kernels' index arithmetic
+(csrc/common/index_math.h), checked on the host over the whole domain the kernels
+use.  A wrong LDS swizzle or tile order would not fail loudly on the GPU, so the
+maps are compiled for the host as well and tested exhaustively here."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from nanofed_amd import native_build
+
+
+@pytest.fixture(scope="module")
+def ix():
+    native_build.build_host()
+    lib = ctypes.CDLL(str(native_build.HOST_LIB))
+    for name in ("gemm_kc_off", "gemm_km_off", "gemm_tile_index", "mnist_fwd_swz", "mnist_dg_swz",
+                 "mfma32_acc_row", "conv_patch_source", "conv_patch_index"):
+        getattr(lib, f"nf_ix_{name}").restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("rows", [128, 256])
+def test_gemm_k_contiguous_tile_is_a_bijection_onto_its_bytes(ix, rows):
+    # a stage holds `rows` rows of 64 k = 8 pieces of 16 bytes
+    offs = np.array([[ix.nf_ix_gemm_kc_off(r, c) for c in range(8)] for r in range(rows)])
+    assert offs.min() == 0 and offs.max() == rows * 128 - 16 and (offs % 16 == 0).all()
+    assert len(np.unique(offs)) == rows * 8
+    # a piece never leaves its row (the DMA writes rows linearly, the swizzle permutes within)
+    assert ((offs // 128) == np.arange(rows)[:, None]).all()
+    # the 8 lanes that read one k piece of 8 consecutive row pairs hit 8 distinct bank groups
+    for chunk in range(8):
+        groups = {(ix.nf_ix_gemm_kc_off(r, chunk) % 128) // 16 for r in range(0, 16, 2)}
+        assert len(groups) == 8
+
+
+@pytest.mark.parametrize("x", [128, 256])
+def test_gemm_k_major_tile_is_a_bijection_onto_its_bytes(ix, x):
+    rowb = x * 2  # bf16
+    offs = np.array([[ix.nf_ix_gemm_km_off(rowb, k, xb) for xb in range(0, rowb, 8)] for k in range(64)])
+    assert offs.min() == 0 and offs.max() == 64 * rowb - 8 and (offs % 8 == 0).all()
+    assert len(np.unique(offs)) == offs.size
+    assert ((offs // rowb) == np.arange(64)[:, None]).all()
+    # 16-byte pieces stay whole: byte xb and xb + 8 of an aligned piece are neighbours
+    for k in range(64):
+        for xb in range(0, rowb, 16):
+            assert ix.nf_ix_gemm_km_off(rowb, k, xb + 8) == ix.nf_ix_gemm_km_off(rowb, k, xb) + 8
+
+
+@pytest.mark.parametrize("total", [1, 7, 8, 9, 36, 63, 64, 65, 200, 393, 1571])
+def test_every_tile_is_owned_by_exactly_one_workgroup(ix, total):
+    tiles = [ix.nf_ix_gemm_tile_index(i, total) for i in range(total)]
+    assert sorted(tiles) == list(range(total))
+    # the ids of one XCD (congruent mod 8) own one contiguous range
+    for xcd in range(min(8, total)):
+        mine = [tiles[i] for i in range(xcd, total, 8)]
+        assert mine == list(range(mine[0], mine[0] + len(mine)))
+
+
+def test_mnist_forward_band_image(ix):
+    # a band: 10 rows of 26 pixels, 64 bytes each (the kernel stages 260 pixels)
+    offs = np.array([[ix.nf_ix_mnist_fwd_swz(p, p % 26, ch) for ch in range(4)] for p in range(260)])
+    assert offs.min() == 0 and offs.max() == 260 * 64 - 16 and (offs % 16 == 0).all()
+    assert len(np.unique(offs)) == 260 * 4
+    assert ((offs // 64) == np.arange(260)[:, None]).all()
+
+
+def test_mnist_dgrad_patch(ix):
+    offs = np.array([[[ix.nf_ix_mnist_dg_swz(pr, pc, part) for part in range(8)]
+                      for pc in range(28)] for pr in range(13)])
+    assert offs.min() == 0 and offs.max() == 13 * 28 * 128 - 16 and (offs % 16 == 0).all()
+    assert len(np.unique(offs)) == offs.size
+    pix = np.arange(13)[:, None] * 28 + np.arange(28)[None, :]
+    assert ((offs // 128) == pix[:, :, None]).all()
+    # 8 consecutive pixels of a row read the same part from 8... at least 4 distinct 16-byte
+    # slots per 4 pixels (two pixels share a pair index by construction)
+    for pr in range(13):
+        for part in range(8):
+            slots = [(ix.nf_ix_mnist_dg_swz(pr, pc, part) % 128) // 16 for pc in range(0, 16, 2)]
+            assert len(set(slots)) == 8
+
+
+def test_accumulator_rows_cover_the_tile_once(ix):
+    seen = set()
+    for lane in range(64):
+        for reg in range(16):
+            row = ix.nf_ix_mfma32_acc_row(reg, lane)
+            assert 0 <= row < 32
+            seen.add((row, lane & 31))
+    assert len(seen) == 32 * 32
+
+
+@pytest.mark.parametrize("H,W,RI,NI", [(32, 32, 4, 1), (16, 16, 8, 1), (8, 8, 8, 2), (4, 4, 4, 8)])
+def test_conv_patch_maps_stay_inside_the_tensor_and_the_patch(ix, H, W, RI, NI):
+    B, Cin = 16, 64  # a tile spans NI * RI image rows; the batch is a multiple of that
+    logH, logW, logRI = H.bit_length() - 1, W.bit_length() - 1, RI.bit_length() - 1
+    patch = NI * (RI + 2) * (W + 2)
+    rows_per_tile = NI * RI
+    for row0 in range(0, B * H, rows_per_tile):
+        sources = [ix.nf_ix_conv_patch_source(H, W, logH, RI, Cin, row0, pp) for pp in range(patch)]
+        inside = [s for s in sources if s >= 0]
+        assert all(0 <= s <= (B * H * W - 1) * Cin and s % Cin == 0 for s in inside)
+        assert len(set(inside)) == len(inside)
+        # every output pixel's 3x3 neighbourhood lies inside the patch and its centre is the pixel
+        for m in range(rows_per_tile * W):
+            p = ix.nf_ix_conv_patch_index(W, logW, RI, logRI, m)
+            corners = [p + dy * (W + 2) + dx for dy in range(3) for dx in range(3)]
+            assert 0 <= min(corners) and max(corners) < patch
+            centre = sources[p + (W + 2) + 1]
+            grow = row0 + m // W
+            assert centre == ((grow // H * H + grow % H) * W + m % W) * Cin
