@@ -103,6 +103,14 @@ struct MnistCtx {
     float* dp_c2b;          // [G][B][64] conv2.bias gradient of every sample (DP-SGD)
     int ragged;             // 1: some client runs out of batches before the others
     int cur_step;           // step of the launch (filled in by nf_mnist_stage)
+    // Batches larger than B: an optimisation step is `micro` consecutive table steps
+    // (micro-batches of up to B samples) whose gradients are added up in `grad` before
+    // one SGD update; ntotal holds, per table step, the valid samples of the whole batch
+    // (the divisor of the mean loss).  micro == 1 and ntotal == nullptr: a table step is
+    // an optimisation step.
+    int micro;
+    int accumulate;         // this launch adds to `grad` instead of overwriting it (filled in per micro-batch)
+    const int32_t* ntotal;  // [G][nvalid_stride] or nullptr
 };
 
 }  // extern "C"
@@ -441,7 +449,8 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         float se = 0.f;
         for (int o = 0; o < 10; ++o) se += __expf(lg[tid][o] - m);
         const float lse = m + __logf(se);
-        const float inv = nv > 0 ? 1.0f / static_cast<float>(nv) : 0.f;
+        const int nt = c.ntotal != nullptr ? c.ntotal[g * c.nvalid_stride + step] : nv;
+        const float inv = nt > 0 ? 1.0f / static_cast<float>(nt) : 0.f;
         for (int o = 0; o < 10; ++o) {
             const float p = __expf(lg[tid][o] - lse);
             dl[tid][o] = valid ? (p - (o == y ? 1.f : 0.f)) * inv : 0.f;
@@ -658,11 +667,19 @@ __device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int 
         }
     } else {
         float* gr = c.grad + g * c.grad_stride + c.off_f1w + col;
+        if (c.accumulate) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                gr[static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K] = acc[mb][r];
+                for (int r = 0; r < 16; ++r)
+                    gr[static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K] += acc[mb][r];
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    gr[static_cast<long>(mb * 32 + acc_row(r, lane)) * kFc1K] = acc[mb][r];
+        }
     }
 }
 
@@ -1158,11 +1175,13 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
     if (wave != 0) return;
     s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (metric >= 0 && nv > 0) {
+        // mean over the whole batch; a batch is counted once, with its first micro-batch
+        const int nt = c.ntotal != nullptr ? c.ntotal[g * c.nvalid_stride + step] : nv;
         float* m = c.metrics + g * 4;
-        if (metric == 0) { m[0] += s / nv; m[2] += 1.0f; }
-        else m[1] += s / nv;
+        if (metric == 0) { m[0] += s / nt; if (!c.accumulate) m[2] += 1.0f; }
+        else m[1] += s / nt;
     }
-    if (dst >= 0) gr[dst] = s;
+    if (dst >= 0) gr[dst] = (!kSgd && c.accumulate) ? gr[dst] + s : s;
     if (kSgd && nv > 0) {
         if (dst >= 0) {
             if (c.dp_pass == 2 && c.dp_noise_std > 0.f) {
@@ -1259,6 +1278,8 @@ inline int check_ctx(const MnistCtx* c) {
     if (c->split != 1 && c->split != 3) return -7;
     if (c->conv1_split != 1 && c->conv1_split != 2 && c->conv1_split != 4) return -8;
     if (c->n_arena % 64 != 0) return -5;
+    if (c->micro < 1 || (c->micro > 1 && (c->fuse_sgd || c->dp_pass != 0 || c->ntotal == nullptr)))
+        return -13;
     if (c->dp_pass != 0 &&
         (c->WPC != c->B || c->split != 1 || c->dp_normsq == nullptr ||
          c->dp_rowscale == nullptr || c->dp_c2b == nullptr))
@@ -1277,7 +1298,8 @@ int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
 // stage: 0 conv1_fwd, 1 conv2_fwd, 2 fc1_fwd, 3 head, 4 fc1_dgrad, 5 fc1_wgrad,
 //        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only,
 //        11 dp_scale, 12 finalize + SGD of everything but fc1.weight (fuse_sgd only),
-//        13 conv2_dgrad + fc1_wgrad in one launch
+//        13 conv2_dgrad + fc1_wgrad in one launch, 14 advance the step counters,
+//        15 sgd_pack without advancing the counters
 int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
     const int rc = check_ctx(c);
     if (rc) return rc;
@@ -1319,6 +1341,8 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
         hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0);
         hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1024), 0, s, *c, step);
         break;
+    case 14: hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1024), 0, s, *c, step); break;
+    case 15: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 0); break;
     case 11: hipLaunchKernelGGL(dp_scale_kernel, img_grid, dim3(256), 0, s, *c, step); break;
     case 10: hipLaunchKernelGGL(sgd_pack_kernel, dim3(128, c->G), dim3(256), 0, s, *c, step, 1); break;
     default: return -10;
@@ -1369,8 +1393,35 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     return 0;
 }
 
+// One optimisation step made of ctx->micro micro-batches (table steps step * micro ...):
+// forward and backward per micro-batch with the gradients added up in ctx->grad, the
+// step counters (dropout streams) advanced after each, then one SGD update.
+static int train_step_micro(const MnistCtx* c, int step, hipStream_t s) {
+    MnistCtx p = *c;
+    for (int mb = 0; mb < c->micro; ++mb) {
+        const int ts = step * c->micro + mb;
+        p.accumulate = mb > 0 ? 1 : 0;
+        for (int stage = 0; stage <= 8; ++stage) {
+            const int rc = nf_mnist_stage(&p, stage, ts * c->B, ts, s);
+            if (rc) return rc;
+        }
+        const int rc = nf_mnist_stage(&p, 14, 0, ts, s);
+        if (rc) return rc;
+    }
+    p.accumulate = 0;
+    // the batch is empty exactly when its first micro-batch is
+    return nf_mnist_stage(&p, 15, 0, step * c->micro, s);
+}
+
 // `steps` consecutive optimisation steps (one epoch) in one call.
 int nf_mnist_train_steps(const MnistCtx* c, int first_step, int steps, hipStream_t s) {
+    if (c->micro > 1) {
+        for (int i = 0; i < steps; ++i) {
+            const int rc = train_step_micro(c, first_step + i, s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     for (int i = 0; i < steps; ++i) {
         const int rc = nf_mnist_train_step(c, (first_step + i) * c->B, first_step + i, s);
         if (rc) return rc;

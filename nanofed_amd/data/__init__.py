@@ -9,6 +9,7 @@ from .synthetic import (
     synthetic_cifar10,
     synthetic_images,
     synthetic_mnist,
+    synthetic_mnist_hard,
     synthetic_tokens,
 )
 
@@ -23,6 +24,7 @@ __all__ = [
     "label_histogram",
     "synthetic_images",
     "synthetic_mnist",
+    "synthetic_mnist_hard",
     "synthetic_cifar10",
     "synthetic_tokens",
 ]

@@ -25,6 +25,7 @@ from nanofed_amd.data import (
     sized_partition,
     synthetic_cifar10,
     synthetic_mnist,
+    synthetic_mnist_hard,
     synthetic_tokens,
 )
 from nanofed_amd.data.mnist import MNIST_MEAN, MNIST_STD, load_mnist_arrays
@@ -62,10 +63,11 @@ def build_federated_data(cfg: EngineConfig) -> FederatedData:
     builds the same object and keeps only its clients' shards on its GPU."""
     sizes = _sizes(cfg)
     total = sum(sizes)
-    if cfg.dataset in ("synthetic_mnist", "mnist", "synthetic_cifar10"):
-        if cfg.dataset == "synthetic_mnist":
-            x, y = synthetic_mnist(total, seed=cfg.seed)
-            ex, ey = synthetic_mnist(cfg.eval_samples, seed=cfg.seed + 1)
+    if cfg.dataset in ("synthetic_mnist", "synthetic_mnist_hard", "mnist", "synthetic_cifar10"):
+        if cfg.dataset in ("synthetic_mnist", "synthetic_mnist_hard"):
+            make = synthetic_mnist if cfg.dataset == "synthetic_mnist" else synthetic_mnist_hard
+            x, y = make(total, seed=cfg.seed)
+            ex, ey = make(cfg.eval_samples, seed=cfg.seed + 1)
             mean, std = (MNIST_MEAN,), (MNIST_STD,)
         elif cfg.dataset == "mnist":
             x, y = load_mnist_arrays(cfg.data_dir, train=True, synthetic_fallback=True)

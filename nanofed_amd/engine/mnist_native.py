@@ -86,6 +86,7 @@ class MnistCtx(ctypes.Structure):
         ("dp_clip", c_float), ("dp_noise_std", c_float),
         ("dp_normsq", c_void_p), ("dp_rowscale", c_void_p), ("dp_c2b", c_void_p),
         ("ragged", c_int), ("cur_step", c_int),
+        ("micro", c_int), ("accumulate", c_int), ("ntotal", c_void_p),
     ]
 
 
@@ -111,15 +112,25 @@ def _lib():
     return lib
 
 
+MAX_MICRO = 16  # batch sizes up to 16 * 64
+
+
+def micro_batches(batch_size: int) -> int:
+    """Micro-batches of up to ``BATCH`` rows that make up one batch."""
+    return max(1, -(-batch_size // BATCH))
+
+
 def supports(cfg: EngineConfig) -> bool:
     """True when the hand-written kernels cover ``cfg`` (the engine's ``auto``
-    backend then takes this trainer instead of the PyTorch one)."""
-    return (
-        cfg.model == "mnist_cnn"
-        and cfg.batch_size == BATCH
-        and (cfg.dp is None or cfg.dp.mode == "per_sample")
-        and not cfg.model_kwargs
-    )
+    backend then takes this trainer instead of the PyTorch one).  The kernels
+    work on 64 rows at a time: a smaller batch is one partly filled pass, a
+    larger one several passes whose gradients are added up before the SGD
+    update.  DP-SGD is built for the batch of 64."""
+    if cfg.model != "mnist_cnn" or cfg.model_kwargs:
+        return False
+    if cfg.dp is not None:
+        return cfg.dp.mode == "per_sample" and cfg.batch_size == BATCH
+    return 1 <= cfg.batch_size <= MAX_MICRO * BATCH
 
 
 def native_permutations() -> dict[str, torch.Tensor]:
@@ -158,6 +169,7 @@ class NativeBuffers:
         dp=None,
         parent: "NativeBuffers | None" = None,
         first: int = 0,
+        micro: int = 1,
     ) -> None:
         """``parent`` / ``first``: build a view of clients [first, first + G) of an
         existing set of buffers - same memory (batches, activations, counters,
@@ -167,6 +179,10 @@ class NativeBuffers:
             raise DeviceError("the native MNIST trainer needs a HIP device")
         B = BATCH
         self.G, self.device, self.max_steps = G, device, max(1, max_steps)
+        self.micro = micro
+        if micro > 1 and (dp is not None or not train):
+            raise DeviceError("micro-batch accumulation is for plain SGD training")
+        table_steps = self.max_steps * micro
 
         def z(*shape, dtype=torch.float32, name=None):
             if parent is not None and name is not None:
@@ -177,8 +193,9 @@ class NativeBuffers:
         if self.images.dtype != torch.uint8 or self.images.shape[1] != 784:
             raise DeviceError("native MNIST trainer expects uint8 [N, 784] images")
         self.labels = labels.to(device=device, dtype=torch.int32).contiguous()
-        self.idx = z(G, self.max_steps * B, dtype=torch.int32, name="idx")
-        self.nvalid = z(G, self.max_steps, dtype=torch.int32, name="nvalid")
+        self.idx = z(G, table_steps * B, dtype=torch.int32, name="idx")
+        self.nvalid = z(G, table_steps, dtype=torch.int32, name="nvalid")
+        self.ntotal = z(G, table_steps, dtype=torch.int32, name="ntotal")
         self.shadow = z(G, layout.numel, dtype=torch.bfloat16, name="shadow")
         self.w2t = z(G, 9 * 32 * 64, dtype=torch.bfloat16, name="w2t")
         self.a1 = z(G, B, 676, 32, dtype=torch.bfloat16, name="a1")
@@ -265,7 +282,11 @@ class NativeBuffers:
         c.c2b_part = self.c2b_part.data_ptr()
         # the SGD update of fc1.weight is applied by fc1_wgrad itself (DP-SGD: in the
         # clipped pass, noise included; the other parameters by finalize)
-        c.fuse_sgd = 1 if (train and fuse_sgd) else 0
+        # (micro-batches: the gradients are added up in the gradient arena first)
+        c.fuse_sgd = 1 if (train and fuse_sgd and micro == 1) else 0
+        c.micro = micro
+        c.ntotal = self.ntotal.data_ptr() if (train and (micro > 1 or cfg is not None
+                                               and cfg.batch_size < BATCH)) else 0
         c.dp_normsq, c.dp_rowscale = self.dp_normsq.data_ptr(), self.dp_rowscale.data_ptr()
         c.dp_c2b = self.dp_c2b.data_ptr()
         if dp is not None and train:
@@ -318,8 +339,12 @@ class MnistCnnNativeTrainer(GroupTrainer):
     ) -> None:
         if cfg.model != "mnist_cnn":
             raise DeviceError("the native trainer implements the MNIST CNN only")
-        if cfg.batch_size != BATCH:
-            raise DeviceError(f"the native MNIST trainer is built for batch size {BATCH}")
+        if not supports(cfg):
+            raise DeviceError(
+                f"the native MNIST trainer covers batch sizes 1..{MAX_MICRO * BATCH} "
+                f"(DP-SGD: {BATCH}) of the reference architecture"
+            )
+        self.micro = micro_batches(cfg.batch_size)
         if not pool.layout.perms:
             raise DeviceError("the arena pool must use MnistCnnNativeTrainer.make_layout")
         self.cfg, self.pool, self.shards = cfg, pool, shards
@@ -331,7 +356,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
             pool.layout, G, self.device, shards.inputs, shards.labels, pool.data,
             pool.layout.numel, pool.grad, self.max_steps, mean, std, cfg,
             client_base=shards.client_ids[0] if shards.client_ids else 0,
-            train=True, seed=cfg.seed, dp=cfg.dp,
+            train=True, seed=cfg.seed, dp=cfg.dp, micro=self.micro,
         )
         self._accountants = None
         if cfg.dp is not None:
@@ -348,13 +373,32 @@ class MnistCnnNativeTrainer(GroupTrainer):
             self._accountants = [
                 SubsampledRDPAccountant(pc, dataset_size=max(n, 1)) for n in shards.sizes
             ]
-        B = BATCH
-        nvalid = torch.zeros(G, self.max_steps, dtype=torch.int32)
+        # Tables per client: table step t = s * micro + j is micro-batch j of batch s and
+        # holds samples [s * batch + j * 64, ...) of the epoch's permutation.
+        B, m, bs = BATCH, self.micro, cfg.batch_size
+        T = self.max_steps * m
+        nvalid = torch.zeros(G, T, dtype=torch.int32)
+        ntotal = torch.zeros(G, T, dtype=torch.int32)
+        t = torch.arange(T)
+        lane = torch.arange(B)
+        # position in the permutation of row `lane` of table step t, and whether the
+        # batch reaches that far
+        pos = ((t // m) * bs + (t % m) * B).unsqueeze(1) + lane.unsqueeze(0)        # [T, B]
+        in_batch = ((t % m) * B).unsqueeze(1) + lane.unsqueeze(0) < bs
+        self._gather_pos, self._gather_ok = [], []
         for k in range(G):
-            n, steps = shards.sizes[k], shards.steps_per_epoch(k)
-            for s in range(steps):
-                nvalid[k, s] = min(B, n - s * B)
+            n = shards.sizes[k]
+            ok = in_batch & (pos < n)
+            if shards.drop_last:
+                full = ((t // m) + 1) * bs <= n
+                ok = ok & full.unsqueeze(1)
+            nvalid[k] = ok.sum(dim=1).to(torch.int32)
+            per_batch = nvalid[k].view(self.max_steps, m).sum(dim=1)
+            ntotal[k] = per_batch.repeat_interleave(m)
+            self._gather_pos.append(torch.where(ok, pos, torch.zeros_like(pos)).reshape(-1).to(self.device))
+            self._gather_ok.append(ok.reshape(-1).to(self.device))
         self.buf.nvalid.copy_(nvalid)
+        self.buf.ntotal.copy_(ntotal)
         # unequal shards: the kernels skip a client's workgroups once it has no batch left
         self.buf.ctx.ragged = int(bool((nvalid == 0).any()))
         self.metrics = torch.zeros(G, METRIC_COLUMNS, dtype=torch.float32, device=self.device)
@@ -376,6 +420,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
                     pool.grad[first:] if pool.grad is not None else None, self.max_steps,
                     mean, std, cfg, client_base=shards.client_ids[first] if shards.client_ids else first,
                     train=True, seed=cfg.seed, dp=cfg.dp, parent=self.buf, first=first,
+                    micro=self.micro,
                 )
                 grp.ctx.ragged = int(bool((nvalid[first : first + gs] == 0).any()))
                 self._groups.append(grp)
@@ -401,9 +446,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
         # numbers the dropout and noise streams) restarts every round from
         # round * local_epochs * steps, so a rolled-back or resumed run draws the
         # same streams as an uninterrupted one and nothing has to be checkpointed
-        self._steps_per_epoch = torch.tensor(
-            [shards.steps_per_epoch(k) for k in range(G)], dtype=torch.int64, device=self.device
-        )
+        self._steps_per_epoch = (nvalid > 0).sum(dim=1).to(dtype=torch.int64, device=self.device)
 
     @staticmethod
     def _group_sizes(G: int) -> list[int]:
@@ -417,11 +460,9 @@ class MnistCnnNativeTrainer(GroupTrainer):
         target = self.buf.idx if into is None else into
         for k in range(len(self.pool)):
             perm = self.shards.epoch_permutation(k, round_idx, epoch).to(torch.int32)
-            row = target[k]
-            n = perm.numel()
-            row[:n] = perm
-            if n < row.numel():
-                row[n:] = perm[0]
+            # rows beyond the batch or the shard repeat the first sample (zero loss weight)
+            row = perm[self._gather_pos[k]]
+            target[k].copy_(torch.where(self._gather_ok[k], row, perm[0]))
 
     # The shuffles of an epoch are a few dozen tiny launches per client.  They are
     # issued on a second stream while the previous epoch's graph is running and

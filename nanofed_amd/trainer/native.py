@@ -6,7 +6,9 @@ there) builds a model, a ``DataLoader`` and an optimizer and calls
 (nanofed/trainer/base.py:115-198).  When that call describes exactly what the
 native MNIST step implements - an ``MNISTModel`` on a HIP device, batches of 64
 drawn at random from an MNIST-shaped uint8 set, plain SGD, no per-batch callbacks -
-the epoch runs on ``nanofed_amd.engine.mnist_native`` instead of PyTorch ops: the
+(any batch size from 1 to 1024 in fact: the kernels work on 64 rows at a time and
+accumulate larger batches) the epoch runs on ``nanofed_amd.engine.mnist_native``
+instead of PyTorch ops: the
 model's weights are copied into a one-client arena, the epoch is one hipGraph
 replay, and the trained weights are copied back into the module.  Anything else
 takes the PyTorch path unchanged.
@@ -28,7 +30,7 @@ from nanofed_amd.utils import Logger
 
 from .base import TrainingMetrics
 
-NATIVE_BATCH = 64
+MAX_NATIVE_BATCH = 1024  # 16 accumulated passes of 64 rows
 # Client coroutines often run ``train_epoch`` in worker threads
 # (``asyncio.to_thread``).  Native sessions take turns: a hipGraph capture must not
 # see another thread's allocations, and the kernels of one epoch already fill the
@@ -61,7 +63,9 @@ def native_epoch_supported(trainer: Any, model: Any, dataloader: Any, optimizer:
         return False
     if type(model) is not MNISTModel or cfg.max_batches is not None or trainer._callbacks:
         return False
-    if not isinstance(dataloader, DataLoader) or dataloader.batch_size != NATIVE_BATCH:
+    if not isinstance(dataloader, DataLoader) or dataloader.batch_size is None:
+        return False
+    if not 1 <= dataloader.batch_size <= MAX_NATIVE_BATCH:
         return False
     if dataloader.drop_last or not isinstance(dataloader.sampler, RandomSampler):
         return False
@@ -98,8 +102,9 @@ class NativeEpochSession:
         self.samples = n
         self.lr, self.wd = float(lr), float(wd)
         self.device = device
+        batch = int(dataloader.batch_size)
         cfg = EngineConfig(
-            model="mnist_cnn", num_clients=1, samples_per_client=n, batch_size=NATIVE_BATCH,
+            model="mnist_cnn", num_clients=1, samples_per_client=n, batch_size=batch,
             local_epochs=1, learning_rate=self.lr, weight_decay=self.wd, dtype="bf16",
             backend="native", seed=seed, eval_samples=0,
         )
@@ -107,7 +112,7 @@ class NativeEpochSession:
                              (float(base.mean),), (float(base.std),))
         self.layout = make_layout(MNISTModel())
         self.pool = ArenaPool(self.layout, 1, device)
-        self.shards = DeviceShards(data, [0], device, NATIVE_BATCH, seed)
+        self.shards = DeviceShards(data, [0], device, batch, seed)
         self.trainer = MnistCnnNativeTrainer(cfg, self.pool, self.shards, data)
         self.steps = self.shards.steps_per_epoch(0)
         self.epochs_run = 0

@@ -52,7 +52,8 @@ def test_only_the_exact_native_step_qualifies(monkeypatch):
     sgd = torch.optim.SGD(model.parameters(), lr=0.1)
     assert native.native_epoch_supported(trainer, model, _loader(), sgd)
     assert native.native_epoch_supported(trainer, model, _loader(subset=list(range(100))), sgd)
-    assert not native.native_epoch_supported(trainer, model, _loader(batch=32), sgd)
+    assert native.native_epoch_supported(trainer, model, _loader(batch=32), sgd)
+    assert not native.native_epoch_supported(trainer, model, _loader(n=4096, batch=2048), sgd)
     assert not native.native_epoch_supported(trainer, model, _loader(shuffle=False), sgd)
     momentum = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
     assert not native.native_epoch_supported(trainer, model, _loader(), momentum)
