@@ -450,10 +450,13 @@ class MnistCnnNativeTrainer(GroupTrainer):
 
     @staticmethod
     def _group_sizes(G: int) -> list[int]:
-        """Pairs of clients (a last single one when G is odd); one group below four."""
-        if G < 4:
+        """Pairs of clients (a last single one when G is odd); one group below four.
+        ``NANOFED_MNIST_GROUP`` overrides the group size (measurements)."""
+        size = int(os.environ.get("NANOFED_MNIST_GROUP", "2"))
+        if G < 4 and "NANOFED_MNIST_GROUP" not in os.environ:
             return [G]
-        return [2] * (G // 2) + ([1] if G % 2 else [])
+        size = max(1, min(size, G))
+        return [size] * (G // size) + ([G % size] if G % size else [])
 
     # -- batches ----------------------------------------------------------
     def _fill_indices(self, round_idx: int, epoch: int, into: torch.Tensor | None = None) -> None:
@@ -543,7 +546,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
             # whose training is rolled back anyway; eager: the first epochs of training).
             from nanofed_amd.utils.streams import make_streams
 
-            streams = make_streams(min(len(self._groups), 4), self.device)
+            streams = make_streams(
+                min(len(self._groups), int(os.environ.get("NANOFED_MNIST_STREAMS", "4"))), self.device)
             t0 = torch.cuda.Event(enable_timing=True)
             t1 = torch.cuda.Event(enable_timing=True)
             t0.record(main)

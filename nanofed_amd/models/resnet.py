@@ -34,13 +34,14 @@ class BasicBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # BatchNorm, the residual add and the ReLU are one fused op on the GPU; the
-        # stride-1 3x3 convolutions run on the hand-written MFMA kernels there
+        # stride-1 3x3 convolutions run on the implicit-GEMM MFMA kernels there, the
+        # strided, 1x1 and stem convolutions as patch gather + GEMM
         y, sums = conv2d(self.conv1, x, with_sums=True)  # sums: BatchNorm's statistics
         out = batch_norm_act(self.bn1, y, partials=sums)
         if len(self.shortcut) == 0:
             short = x
         else:
-            short = batch_norm_act(self.shortcut[1], self.shortcut[0](x), relu=False)
+            short = batch_norm_act(self.shortcut[1], conv2d(self.shortcut[0], x), relu=False)
         y, sums = conv2d(self.conv2, out, with_sums=True)
         return batch_norm_act(self.bn2, y, residual=short, partials=sums)
 
@@ -65,7 +66,7 @@ class ResNet18(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = batch_norm_act(self.bn1, self.conv1(x))
+        x = batch_norm_act(self.bn1, conv2d(self.conv1, x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
         return self.fc(x)
