@@ -223,44 +223,85 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // One K step from stage `cur`, two 16-deep MFMA groups at a time: all fragments of
-    // the two groups are requested first (their LDS latency overlaps), then multiplied.
-    auto step = [&](int cur) {
+    // A quarter of a K step (one 16-deep MFMA group) from stage `cur`
+    auto step_quarter = [&](int cur, int s) {
         const char* sa = smem + cur * G::STAGE;
         const char* sb = sa + G::TILE_A;
+        bf16x8 af[RM], bfr[RN];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            bf16x8 af[2][RM], bfr[2][RN];
+        for (int i = 0; i < RM; ++i) {
+            const int r0 = wm * (BM / G::WM) + i * 32;
+            if (!A_KM) af[i] = *reinterpret_cast<const bf16x8*>(sa + kc_off(r0 + n, 2 * s + h));
+            else af[i] = km_frag<BM * 2>(sa, s * 16, r0, lane);
+        }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int s = 2 * half + u;
+        for (int j = 0; j < RN; ++j) {
+            const int c0 = wn * (BN / G::WN) + j * 32;
+            if (!B_KM) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + kc_off(c0 + n, 2 * s + h));
+            else bfr[j] = km_frag<BN * 2>(sb, s * 16, c0, lane);
+        }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < RM; ++i) {
-                    const int r0 = wm * (BM / G::WM) + i * 32;
-                    if (!A_KM) af[u][i] = *reinterpret_cast<const bf16x8*>(sa + kc_off(r0 + n, 2 * s + h));
-                    else af[u][i] = km_frag<BM * 2>(sa, s * 16, r0, lane);
-                }
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
-                for (int j = 0; j < RN; ++j) {
-                    const int c0 = wn * (BN / G::WN) + j * 32;
-                    if (!B_KM) bfr[u][j] = *reinterpret_cast<const bf16x8*>(sb + kc_off(c0 + n, 2 * s + h));
-                    else bfr[u][j] = km_frag<BN * 2>(sb, s * 16, c0, lane);
-                }
+            for (int j = 0; j < RN; ++j)
+                acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // Half a K step (two 16-deep groups): all fragments of the two groups are requested
+    // first (their LDS latency overlaps), then multiplied.  Operands read through the
+    // transposing LDS loads take this form: two instructions per fragment, more latency
+    // to cover per group.
+    auto step_half = [&](int cur, int half) {
+        const char* sa = smem + cur * G::STAGE;
+        const char* sb = sa + G::TILE_A;
+        bf16x8 af[2][RM], bfr[2][RN];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = 2 * half + u;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int r0 = wm * (BM / G::WM) + i * 32;
+                if (!A_KM) af[u][i] = *reinterpret_cast<const bf16x8*>(sa + kc_off(r0 + n, 2 * s + h));
+                else af[u][i] = km_frag<BM * 2>(sa, s * 16, r0, lane);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j)
-                        acc[i][j] = mfma32(af[u][i], bfr[u][j], acc[i][j]);
+            for (int j = 0; j < RN; ++j) {
+                const int c0 = wn * (BN / G::WN) + j * 32;
+                if (!B_KM) bfr[u][j] = *reinterpret_cast<const bf16x8*>(sb + kc_off(c0 + n, 2 * s + h));
+                else bfr[u][j] = km_frag<BN * 2>(sb, s * 16, c0, lane);
+            }
         }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    acc[i][j] = mfma32(af[u][i], bfr[u][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto step = [&](int cur) {
+        step_half(cur, 0);
+        step_half(cur, 1);
+    };
+    // first (part 0) or second (part 1) half of this wave's DMAs of one K step
+    auto issue_part = [&](int kt, int stage, int part) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            if ((p & 1) == part || PA == 1)
+                if (PA > 1 || part == 0)
+                    dma16(g.A + (srca[p] + kt * stepa), dsta + stage * G::STAGE + p * 1024);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            if ((p & 1) == part || PB == 1)
+                if (PB > 1 || part == 1)
+                    dma16(g.B + (srcb[p] + kt * stepb), dstb + stage * G::STAGE + p * 1024);
     };
     auto issue_all = [&](int kt, int stage) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) dma16(g.A + (srca[p] + kt * stepa), dsta + stage * G::STAGE + p * 1024);
-#pragma unroll
-        for (int p = 0; p < PB; ++p) dma16(g.B + (srcb[p] + kt * stepb), dstb + stage * G::STAGE + p * 1024);
+        issue_part(kt, stage, 0);
+        issue_part(kt, stage, 1);
     };
 
     if (nk > 0) {
@@ -272,8 +313,25 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
         for (int t = 0; t < nk; ++t) {
             wait_vmcnt<(D - 1) * (PA + PB)>();
             __builtin_amdgcn_s_barrier();  // step t is in LDS for everybody; step t - 1 has been read
-            issue_all(min(ks0 + t + D, kf1 - 1), (t + D) % STAGES);
-            step(t % STAGES);
+            // The two waves of a SIMD take turns: one issues its DMAs (a few hundred issue
+            // cycles during which it feeds no MFMA) while the other multiplies, then the
+            // other way round.  (The count that wait_vmcnt relies on is per wave and the
+            // same either way.)
+            const int kn = min(ks0 + t + D, kf1 - 1), sn = (t + D) % STAGES, cur = t % STAGES;
+            if (!A_KM && !B_KM) {
+                if (wave < 4) issue_part(kn, sn, 0);
+                step_quarter(cur, 0);
+                issue_part(kn, sn, wave < 4 ? 1 : 0);
+                step_quarter(cur, 1);
+                if (wave >= 4) issue_part(kn, sn, 1);
+                step_quarter(cur, 2);
+                step_quarter(cur, 3);
+            } else {
+                if (wave < 4) issue_all(kn, sn);
+                step_half(cur, 0);
+                if (wave >= 4) issue_all(kn, sn);
+                step_half(cur, 1);
+            }
         }
         wait_vmcnt<0>();
     }
@@ -441,6 +499,7 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restric
 using Geo256 = Geo<256, 256, 2, 2>;      // 128 x 64 per wave, 2 stages of 64 KiB
 using Geo256x128 = Geo<256, 128, 4, 3>;  // 64 x 64 per wave, 3 stages of 48 KiB
 using Geo128 = Geo<128, 128, 2, 4>;      // 64 x 32 per wave, 4 stages of 32 KiB
+using Geo128x2 = Geo<128, 128, 2, 2>;    // the same with 2 stages: two workgroups share a CU
 
 template <class G, bool A_KM, bool B_KM>
 int launch(GemmArgs g, hipStream_t stream) {
@@ -461,6 +520,7 @@ int launch_geo(int geo, const GemmArgs& g, hipStream_t stream) {
     case 0: return launch<Geo128, A_KM, B_KM>(g, stream);
     case 1: return launch<Geo256x128, A_KM, B_KM>(g, stream);
     case 2: return launch<Geo256, A_KM, B_KM>(g, stream);
+    case 3: return launch<Geo128x2, A_KM, B_KM>(g, stream);
     default: return -7;
     }
 }
@@ -469,7 +529,7 @@ int launch_geo(int geo, const GemmArgs& g, hipStream_t stream) {
 
 extern "C" {
 
-int nf_gemm_geometries() { return 3; }
+int nf_gemm_geometries() { return 4; }
 
 // layout: 0 = NT (A [M][K], B [N][K]), 1 = NN (A [M][K], B [K][N]), 2 = TN (A [K][M], B [K][N]).
 // splits > 1: `slabs` must hold splits * M * N floats; the bf16 result is written to C

@@ -61,8 +61,9 @@ def _slab_buffer(dev: torch.device, floats: int) -> torch.Tensor:
     return buf
 
 
-GEO_128, GEO_256x128, GEO_256 = 0, 1, 2
-_GEO_TILE = {GEO_128: (128, 128), GEO_256x128: (256, 128), GEO_256: (256, 256)}
+GEO_128, GEO_256x128, GEO_256, GEO_128_2 = 0, 1, 2, 3
+_GEO_TILE = {GEO_128: (128, 128), GEO_256x128: (256, 128), GEO_256: (256, 256),
+             GEO_128_2: (128, 128)}
 # NANOFED_GEMM_GEO=0|1|2 pins the workgroup tile (measurements)
 _FORCED_GEO = os.environ.get("NANOFED_GEMM_GEO")
 
@@ -70,22 +71,19 @@ _FORCED_GEO = os.environ.get("NANOFED_GEMM_GEO")
 def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0) -> int:
     """Workgroup tile for an ``M x N`` output with reduction length ``K``.  Bigger
     tiles load fewer operand bytes per MFMA but make fewer workgroups and need a
-    long K loop to pay for their prologue.  The thresholds are read off
-    ``tools/bench_gemm.py --geometries`` at the GPT-2-small shapes: operands that
-    are read through the transposing LDS loads (dgrad, wgrad) gain more from large
-    tiles than the forward layout does."""
+    long K loop to pay for their prologue; the 128 x 128 tile with two LDS stages lets
+    two workgroups share a compute unit, so one's prologue and epilogue overlap the
+    other's main loop - the best choice at the GPT-2-small layer shapes in all three
+    layouts.  The thresholds are read off ``tools/bench_gemm.py --geometries``."""
     if _FORCED_GEO is not None:
         return int(_FORCED_GEO)
     ksteps = (K + 63) // 64
     t256 = (-(-M // 256)) * (-(-N // 256))
-    t256x128 = (-(-M // 256)) * (-(-N // 128))
-    if layout == NT:
-        return GEO_256x128 if t256x128 >= 384 else GEO_128
-    if t256 >= 36 and ksteps >= 48:
-        return GEO_256
-    if t256x128 >= 48 and ksteps >= 24:
-        return GEO_256x128
-    return GEO_128
+    if t256 >= 224 and ksteps >= 32 and min(M, N) >= 2048:
+        return GEO_256        # enough 256 x 256 tiles for every CU, a long K loop, both sides wide
+    if t256 >= 1024 and layout == NT:
+        return GEO_256x128    # very wide outputs with a short K loop (the LM head)
+    return GEO_128_2
 
 
 def _launch(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int,

@@ -78,7 +78,7 @@ def main() -> None:
                          "lib_tflops": round(flops / t_lib / 1e6, 1)}
             if args.geometries:
                 per_geo = {}
-                for geo in (0, 1, 2):
+                for geo in (0, 1, 2, 3):
                     gemm_ops._FORCED_GEO = str(geo)
                     per_geo[geo] = round(timed(mine), 2)
                 gemm_ops._FORCED_GEO = None
