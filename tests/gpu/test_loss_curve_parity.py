@@ -11,7 +11,7 @@ from nanofed_amd.parallel import Communicator
 
 pytestmark = pytest.mark.gpu
 
-CFG = dict(model="mnist_cnn", dataset="synthetic_mnist_hard", num_clients=4, samples_per_client=2048,
+CFG = dict(model="mnist_cnn", dataset="synthetic_mnist_hard", num_clients=4, samples_per_client=4096,
            batch_size=64, local_epochs=2, learning_rate=0.1, eval_samples=2000, seed=5)
 
 
@@ -33,9 +33,9 @@ def test_native_bf16_and_torch_fp32_curves_agree_over_three_rounds():
     # the task is learned progressively, by both
     for curve in (native, torch32):
         assert curve[0][0] > curve[1][0] > curve[2][0]
-        assert curve[2][3] > curve[0][3] and 0.5 < curve[2][3] < 0.97
+        assert curve[2][3] > curve[0][3] and 0.6 < curve[2][3] < 0.97
     for r, (a, b) in enumerate(zip(native, torch32)):
-        assert a[0] == pytest.approx(b[0], rel=0.12, abs=0.05), f"train loss, round {r}: {a[0]} vs {b[0]}"
+        assert a[0] == pytest.approx(b[0], rel=0.15, abs=0.08), f"train loss, round {r}: {a[0]} vs {b[0]}"
         assert a[1] == pytest.approx(b[1], abs=0.06), f"train accuracy, round {r}"
         # the model after the first round sits in the steepest part of the curve, where
         # held-out numbers swing with the dropout streams alone (0.63 against 0.77

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread \
     > gpurun_out/gpu_tests.log 2>&1
 rc=$?; tail -3 gpurun_out/gpu_tests.log; [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 rc=$?; cat gpurun_out/bench.json; [ $rc -eq 0 ] || { tail -5 gpurun_out/bench.err; exit $rc; }
 rm -rf gpurun_out/prof_innode
 timeout -k 10 400 rocprofv3 --kernel-trace -d gpurun_out/prof_innode -o innode -- \
