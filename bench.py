@@ -33,7 +33,11 @@ import sys
 import tempfile
 import time
 
-import torch
+# the host driver of these machines supports dmabuf IPC only: without this, RCCL's
+# peer-memory exchange between the ranks of a node fails (hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 BASELINE_ROUNDS_PER_S = 1.0 / 53.48
 

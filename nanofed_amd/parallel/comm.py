@@ -76,6 +76,9 @@ class Communicator:
     ) -> "Communicator":
         """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK /
         MASTER_ADDR / MASTER_PORT (the ``torch.distributed.run`` contract)."""
+        # dmabuf IPC for RCCL's peer-memory exchange (read when the runtime starts, so
+        # it only helps when nothing has touched the GPU yet; launchers should export it)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
