@@ -500,6 +500,9 @@ using Geo256 = Geo<256, 256, 2, 2>;      // 128 x 64 per wave, 2 stages of 64 Ki
 using Geo256x128 = Geo<256, 128, 4, 3>;  // 64 x 64 per wave, 3 stages of 48 KiB
 using Geo128 = Geo<128, 128, 2, 4>;      // 64 x 32 per wave, 4 stages of 32 KiB
 using Geo128x2 = Geo<128, 128, 2, 2>;    // the same with 2 stages: two workgroups share a CU
+using Geo128x192 = Geo<128, 192, 4, 2>;  // 32 x 96 per wave, 2 stages of 40 KiB, two workgroups per CU
+                                         // (k-contiguous operands only: the k-major swizzle needs
+                                         // rows of a multiple of 256 bytes)
 
 template <class G, bool A_KM, bool B_KM>
 int launch(GemmArgs g, hipStream_t stream) {
@@ -521,6 +524,9 @@ int launch_geo(int geo, const GemmArgs& g, hipStream_t stream) {
     case 1: return launch<Geo256x128, A_KM, B_KM>(g, stream);
     case 2: return launch<Geo256, A_KM, B_KM>(g, stream);
     case 3: return launch<Geo128x2, A_KM, B_KM>(g, stream);
+    case 4:
+        if constexpr (!A_KM && !B_KM) return launch<Geo128x192, false, false>(g, stream);
+        else return -7;
     default: return -7;
     }
 }
@@ -529,7 +535,7 @@ int launch_geo(int geo, const GemmArgs& g, hipStream_t stream) {
 
 extern "C" {
 
-int nf_gemm_geometries() { return 4; }
+int nf_gemm_geometries() { return 5; }
 
 // layout: 0 = NT (A [M][K], B [N][K]), 1 = NN (A [M][K], B [K][N]), 2 = TN (A [K][M], B [K][N]).
 // splits > 1: `slabs` must hold splits * M * N floats; the bf16 result is written to C

@@ -61,9 +61,9 @@ def _slab_buffer(dev: torch.device, floats: int) -> torch.Tensor:
     return buf
 
 
-GEO_128, GEO_256x128, GEO_256, GEO_128_2 = 0, 1, 2, 3
+GEO_128, GEO_256x128, GEO_256, GEO_128_2, GEO_128x192 = 0, 1, 2, 3, 4
 _GEO_TILE = {GEO_128: (128, 128), GEO_256x128: (256, 128), GEO_256: (256, 256),
-             GEO_128_2: (128, 128)}
+             GEO_128_2: (128, 128), GEO_128x192: (128, 192)}
 # NANOFED_GEMM_GEO=0|1|2 pins the workgroup tile (measurements)
 _FORCED_GEO = os.environ.get("NANOFED_GEMM_GEO")
 
@@ -83,6 +83,13 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0) -> int:
         return GEO_256        # enough 256 x 256 tiles for every CU, a long K loop, both sides wide
     if t256 >= 1024 and layout == NT:
         return GEO_256x128    # very wide outputs with a short K loop (the LM head)
+    if layout == NT and N % 192 == 0:
+        # k-contiguous operands may use 128 x 192 tiles: when they make about one full
+        # round of workgroups (two per CU) where 128 x 128 tiles make one and a half
+        t192 = (-(-M // 128)) * (N // 192)
+        t128 = (-(-M // 128)) * (-(-N // 128))
+        if 256 <= t192 <= 512 < t128:
+            return GEO_128x192
     return GEO_128_2
 
 

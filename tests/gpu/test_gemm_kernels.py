@@ -119,3 +119,35 @@ def test_operand_checks_fail_loudly():
         gemm_ops.linear_fwd(x[:, :70], rnd(8, 70), None, torch.empty(64, 8, dtype=torch.bfloat16, device="cuda"))
     with pytest.raises(DeviceError):
         gemm_ops.linear_fwd(x.float(), rnd(8, 72), None, torch.empty(64, 8, dtype=torch.bfloat16, device="cuda"))
+
+
+@pytest.mark.parametrize("geo", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 200), (1024, 768, 1536), (129, 193, 77)])
+def test_every_tile_geometry_on_every_layout(geo, M, N, K):
+    from nanofed_amd.core.exceptions import DeviceError
+
+    kp = (K + 7) // 8 * 8
+
+    def padded(t):  # rows padded to a multiple of 8 elements, the padding holding NaNs
+        buf = torch.full((t.shape[0], (t.shape[1] + 7) // 8 * 8), float("nan"),
+                         dtype=torch.bfloat16, device="cuda")
+        buf[:, : t.shape[1]] = t
+        return buf[:, : t.shape[1]]
+
+    a, b = padded(rnd(M, K, seed=geo + 1)), padded(rnd(N, K, scale=0.05, seed=geo + 2))
+    ld = (N + 7) // 8 * 8
+    out = torch.full((M, ld), float("nan"), dtype=torch.bfloat16, device="cuda")[:, :N]
+    gemm_ops._launch(gemm_ops.NT, a, b, out, M, N, K, geo=geo, splits=1)
+    close(out, a.float() @ b.float().t(), K)
+    # the other two layouts: geometry 4 serves k-contiguous operands only
+    dy = padded(rnd(M, N, scale=0.1, seed=9))
+    dx = torch.empty(M, kp, dtype=torch.bfloat16, device="cuda")[:, :K]
+    if geo == 4:
+        with pytest.raises(DeviceError):
+            gemm_ops._launch(gemm_ops.NN, dy, b, dx, M, K, N, geo=geo, splits=1)
+        return
+    gemm_ops._launch(gemm_ops.NN, dy, b, dx, M, K, N, geo=geo, splits=1)
+    close(dx, dy.float() @ b.float(), N)
+    dw = torch.empty(N, kp, dtype=torch.bfloat16, device="cuda")[:, :K]
+    gemm_ops._launch(gemm_ops.TN, dy, a, dw, N, K, M, geo=geo, splits=1)
+    close(dw, dy.float().t() @ a.float(), M)
