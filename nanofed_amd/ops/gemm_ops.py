@@ -163,20 +163,21 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
 
 def choose_splits(M: int, N: int, K: int, geo: int = GEO_128) -> int:
     """Split factor of a GEMM with ``M x N`` outputs and reduction length ``K``.  A
-    launch with fewer tiles than the chip has compute units is cut along K until the
-    tiles times ranges fill it, provided every range keeps at least 16 K steps of 64
-    (the fp32 slab round trip costs about as much as 10 steps).  Outputs of a few tiles
-    only (weight gradients of small layers: K is the number of pixels or tokens) have
-    almost no slab traffic: they are cut into ranges as short as 4 steps, up to 64."""
+    launch with fewer tiles than the chip has workgroup slots is cut along K until tiles
+    times ranges come to about 430 workgroups (two per CU, a little under two full
+    rounds - measured optimum at the GPT-2-small weight-gradient shapes), provided every
+    range keeps at least 8 K steps of 64.  Outputs of a few tiles only (weight gradients
+    of small layers: K is the number of pixels or tokens) have almost no slab traffic:
+    they are cut into ranges as short as 4 steps, up to 64."""
     bm, bn = _GEO_TILE[geo]
     tiles = (-(-M // bm)) * (-(-N // bn))
     if tiles >= 200:
         return 1
     ksteps = (K + 63) // 64
-    want = -(-256 // tiles)
     if tiles <= 16:
-        return max(1, min(want, 64, ksteps // 4))
-    return max(1, min(want, 16, ksteps // 16))
+        return max(1, min(-(-256 // tiles), 64, ksteps // 4))
+    want = max(1, (432 + tiles // 2) // tiles)
+    return max(1, min(want, 16, ksteps // 8))
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> None:
