@@ -357,7 +357,7 @@ def test_idle_clients_are_skipped_without_changing_the_result():
 
 
 def test_client_groups_train_the_same_model(monkeypatch):
-    """Four clients as two concurrent groups of two against one chain of four.  With
+    """Four clients as four concurrent chains against one chain of four.  With
     the kernel geometry pinned every client's partial sums are formed the same way,
     so the models must agree bit for bit."""
     from nanofed_amd.engine import EngineConfig, FederatedEngine
@@ -371,7 +371,7 @@ def test_client_groups_train_the_same_model(monkeypatch):
                            local_epochs=3, eval_samples=64, backend="native", seed=4,
                            client_streams=groups)
         eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
-        assert len(eng.trainer._groups) == (2 if groups else 1)
+        assert len(eng.trainer._groups) == (4 if groups else 1)
         reps = eng.run(2)   # six epochs: the stream trials and the chosen set
         if groups:
             assert len(eng.trainer._stream_trials) == eng.trainer.STREAM_TRIALS
