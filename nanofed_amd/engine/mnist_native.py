@@ -505,11 +505,12 @@ class MnistCnnNativeTrainer(GroupTrainer):
         counter = self.buf.step_counter.clone()
         self.buf.pack()
         self._fill_indices(round_idx, 0)
-        # Several groups: the host needs about 0.3 ms to enqueue a 118-step graph, so
-        # the groups' epochs would start staggered by that much.  Each group's epoch
-        # is therefore two graphs, a short head and the rest, launched head-first
-        # across the groups (all chains are running while the long graphs go out).
-        head = self.HEAD_STEPS if len(self._groups) > 1 and self.max_steps > self.HEAD_STEPS else 0
+        # The host needs about 0.3 ms to enqueue a 118-step graph, so the groups' epochs
+        # would start staggered by that much (and a single chain would start that late
+        # after the host synchronisation that ends a round).  Each group's epoch is
+        # therefore two graphs, a short head and the rest, launched head-first across
+        # the groups (all chains are running while the long graphs go out).
+        head = self.HEAD_STEPS if self.max_steps > self.HEAD_STEPS else 0
         self._chunks = [(0, head), (head, self.max_steps - head)] if head else [(0, self.max_steps)]
         graphs = []
         for grp in self._groups:
