@@ -55,6 +55,7 @@ from nanofed_amd.models import build_model
 from nanofed_amd.parallel.comm import Communicator
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool, ParameterArena
 from nanofed_amd.utils import Logger, get_current_time
+from nanofed_amd.utils.streams import side_stream
 from nanofed_amd.utils.trace import PhaseTimer
 
 from .config import EngineConfig
@@ -391,7 +392,7 @@ class FederatedEngine:
             for _ in range(n_slots)
         ]
         if pin:
-            self._copy_stream = torch.cuda.Stream(self.device)
+            self._copy_stream = side_stream(self.device)
             self._snap_events = [torch.cuda.Event() for _ in range(n_slots)]
         if self.cfg.async_persist:
             self._persister = _Persister(self._write_job, slots=n_slots - 1)

@@ -28,7 +28,6 @@ from __future__ import annotations
 
 import os
 
-
 import torch
 import torch.nn.functional as F
 
@@ -38,6 +37,7 @@ from nanofed_amd.ops import attention as attn_ops
 from nanofed_amd.ops import gemm_ops
 from nanofed_amd.ops import nn_ops
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
+from nanofed_amd.utils.streams import side_stream
 
 from .config import EngineConfig
 from .data import DeviceShards, FederatedData
@@ -135,7 +135,7 @@ class GPT2NativeTrainer(GroupTrainer):
         self._grads = [torch.zeros(n, dtype=BF16, device=self.device) for _ in range(self.lanes)]
         self._gvs = [_views(self.layout, g) for g in self._grads]
         self._streams = (
-            [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+            [side_stream(self.device) for _ in range(self.lanes)]
             if self.lanes > 1 else None
         )
         self._eval_shadow = torch.zeros(n, dtype=BF16, device=self.device)

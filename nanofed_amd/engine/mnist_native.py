@@ -34,6 +34,7 @@ import torch.nn as nn
 from nanofed_amd.core.exceptions import DeviceError
 from nanofed_amd.ops import library
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
+from nanofed_amd.utils.streams import side_stream
 
 from .config import EngineConfig
 from .data import DeviceShards, FederatedData
@@ -432,7 +433,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
         self._stream_trials: list[tuple[float, list[torch.cuda.Stream]]] = []
         # staging table and (default-priority) side stream for the epoch shuffles
         self._idx_stage = torch.empty_like(self.buf.idx)
-        self._idx_stream = torch.cuda.Stream(self.device) if cfg.graph_capture else None
+        self._idx_stream = side_stream(self.device) if cfg.graph_capture else None
         self._idx_ready = torch.cuda.Event()
         self._idx_consumed = torch.cuda.Event()
         self._idx_consumed.record(torch.cuda.current_stream(self.device))

@@ -35,6 +35,7 @@ import torch.nn.functional as F
 from nanofed_amd import ops
 from nanofed_amd.core.exceptions import DeviceError
 from nanofed_amd.runtime.arena import ArenaPool
+from nanofed_amd.utils.streams import side_stream
 
 from .config import EngineConfig
 from .data import DeviceShards
@@ -157,7 +158,7 @@ class TorchGroupTrainer(GroupTrainer):
             # NANOFED_CLIENT_STREAMS overrides the configured count for experiments
             ns = int(os.environ.get("NANOFED_CLIENT_STREAMS", cfg.client_stream_count))
             ns = max(1, min(len(pool), ns))
-            base = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
+            base = [side_stream(self.device) for _ in range(ns)]
             self._streams = [base[k % ns] for k in range(len(pool))]
         # The convolution library times its kernels per shape once (during the
         # eager warm-up steps) instead of taking its untuned default.  The flag is
@@ -231,7 +232,7 @@ class TorchGroupTrainer(GroupTrainer):
         static_rows = (
             torch.arange(self.cfg.batch_size, device=self.device) + int(self.shards.offsets[k])
         )
-        side = torch.cuda.Stream(device=self.device)
+        side = side_stream(self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):

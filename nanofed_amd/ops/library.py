@@ -9,6 +9,7 @@ silently - a missing or unloadable library raises ``DeviceError``.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
 from functools import lru_cache
 
@@ -89,9 +90,20 @@ def stream_ptr(device: torch.device | None = None) -> c_void_p:
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# NANOFED_DEBUG_SYNC=1: wait for the device after every native launch, so that an
+# asynchronous error (or a hang) is reported at the launch that caused it instead of at
+# some later synchronisation.  Not usable while a stream is being captured into a graph.
+_DEBUG_SYNC = os.environ.get("NANOFED_DEBUG_SYNC", "0") == "1"
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         raise DeviceError(f"{what} failed with HIP/launch status {code}")
+    if _DEBUG_SYNC and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError as exc:
+            raise DeviceError(f"{what}: the device reported an error after the launch: {exc}") from exc
 
 
 def require_flat_f32(t: torch.Tensor, name: str, align: int = 16) -> None:

@@ -14,11 +14,29 @@ longer needs (the trainer tries several sets and keeps one).
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
 _HIP_STREAM_NON_BLOCKING = 0x01
 _owned: set[int] = set()  # handles created here and not yet destroyed
+
+
+def serialized() -> bool:
+    """``NANOFED_SERIALIZE_STREAMS=1`` (debug builds of a run): every side stream of the
+    engine and the trainers is the current stream, so nothing overlaps and every
+    cross-stream dependency is trivially ordered.  A run in this mode must produce the
+    same bits as the normal run; a difference means a missing event or wait somewhere
+    (``tests/gpu/test_stream_ordering.py``)."""
+    return os.environ.get("NANOFED_SERIALIZE_STREAMS", "0") == "1"
+
+
+def side_stream(device: torch.device) -> torch.cuda.Stream:
+    """A stream for work that may overlap the current one (the current stream itself in
+    serialized mode)."""
+    if serialized():
+        return torch.cuda.current_stream(device)
+    return torch.cuda.Stream(device=device)
 
 
 def _runtime() -> ctypes.CDLL:
@@ -40,6 +58,8 @@ def make_streams(n: int, device: torch.device | int | None = None) -> list[torch
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else (
         torch.device(device) if not isinstance(device, int) else torch.device("cuda", device))
     index = dev.index if dev.index is not None else torch.cuda.current_device()
+    if serialized():
+        return [torch.cuda.current_stream(dev)] * n
     out: list[torch.cuda.Stream] = []
     try:
         hip = _runtime()
