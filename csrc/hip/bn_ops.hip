@@ -15,6 +15,14 @@
 //
 // A lane owns 8 adjacent channels (one 16-byte load); a wave covers
 // 64 / (C/8) rows per iteration.  No atomics: results are reproducible.
+//
+// Grouped launches (nf_bn_fwd_g / nf_bn_bwd_g): x holds G independent batches of R
+// rows each, one after the other (the clients of a GPU, every one with its own
+// parameters and statistics); blockIdx.y is the group, parameters of group g live
+// `pstride` floats after those of group g - 1 (rows of a parameter arena), and the
+// parameter gradients can be written as bf16 into rows of a flat gradient buffer.
+// The backward pass optionally takes its incoming gradient as the sum of two tensors
+// (the two branches that consumed a residual block's input).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -71,6 +79,8 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16* x, fl
                                                                long R, int C, int lpr,
                                                                long rows_per_block) {
     extern __shared__ float red[];
+    x += static_cast<long>(blockIdx.y) * R * C;
+    partial += static_cast<long>(blockIdx.y) * gridDim.x * 2 * C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
     const long r0 = blockIdx.x * rows_per_block;
@@ -122,8 +132,14 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* partia
                                                              float* running_var, int nblocks,
                                                              int C, float inv_count,
                                                              float unbias, float momentum,
-                                                             float eps) {
+                                                             float eps, long pstride) {
     float s, q;
+    partial += static_cast<long>(blockIdx.y) * nblocks * 2 * C;
+    stats += static_cast<long>(blockIdx.y) * 2 * C;
+    if (running_mean != nullptr) {
+        running_mean += blockIdx.y * pstride;
+        running_var += blockIdx.y * pstride;
+    }
     const int c = final_sums(partial, nblocks, C, s, q);
     if (c < 0) return;
     const float mean = s * inv_count;
@@ -140,7 +156,16 @@ template <bool kRelu, bool kRes>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16* x, const bf16* res,
                                                        const float* stats, const float* gamma,
                                                        const float* beta, bf16* y, long n8,
-                                                       int C) {
+                                                       int C, long pstride) {
+    {
+        const long gofs = static_cast<long>(blockIdx.y) * n8 * 8;
+        x += gofs;
+        y += gofs;
+        if (kRes) res += gofs;
+        stats += static_cast<long>(blockIdx.y) * 2 * C;
+        gamma += blockIdx.y * pstride;
+        beta += blockIdx.y * pstride;
+    }
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
          i += static_cast<long>(gridDim.x) * 256) {
         const int c0 = static_cast<int>((i * 8) % C);
@@ -165,12 +190,33 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16* x, const bf16
     }
 }
 
+// gradient arriving at the layer: dy (+ dy2 when the layer's output fed two branches)
+__device__ __forceinline__ void load_dy(const bf16* dy, const bf16* dy2, long at, float (&d)[8]) {
+    load8(dy + at, d);
+    if (dy2 != nullptr) {
+        float e[8];
+        load8(dy2 + at, e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] += e[k];
+    }
+}
+
 template <bool kRelu>
-__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const bf16* dy, const bf16* y,
-                                                             const bf16* x, const float* stats,
-                                                             float* partial, long R, int C,
-                                                             int lpr, long rows_per_block) {
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const bf16* dy, const bf16* dy2,
+                                                             const bf16* y, const bf16* x,
+                                                             const float* stats, float* partial,
+                                                             long R, int C, int lpr,
+                                                             long rows_per_block) {
     extern __shared__ float red[];
+    {
+        const long gofs = static_cast<long>(blockIdx.y) * R * C;
+        dy += gofs;
+        if (dy2 != nullptr) dy2 += gofs;
+        x += gofs;
+        if (kRelu) y += gofs;
+        stats += static_cast<long>(blockIdx.y) * 2 * C;
+        partial += static_cast<long>(blockIdx.y) * gridDim.x * 2 * C;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
     const long r0 = blockIdx.x * rows_per_block;
@@ -186,7 +232,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const bf16* dy, con
     for (long r = r0 + wave * rpw + sub; r < r1; r += 4 * rpw) {
         const long at = r * C + chunk * 8;
         float d[8], xv[8];
-        load8(dy + at, d);
+        load_dy(dy, dy2, at, d);
         load8(x + at, xv);
         if (kRelu) {
             float yv[8];
@@ -203,29 +249,53 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const bf16* dy, con
     reduce_and_store(sb, sg, lpr, C, partial, red);
 }
 
-// coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat); d(gamma), d(beta) are overwritten.
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat); d(gamma), d(beta) are overwritten
+// (fp32, or bf16 when out_bf16 is set; group g writes ostride elements after group g - 1).
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* partial, float* coef,
-                                                           float* dgamma, float* dbeta,
-                                                           int nblocks, int C, float inv_count) {
+                                                           void* dgamma, void* dbeta,
+                                                           int nblocks, int C, float inv_count,
+                                                           int out_bf16, long ostride) {
     float sb, sg;
+    partial += static_cast<long>(blockIdx.y) * nblocks * 2 * C;
+    coef += static_cast<long>(blockIdx.y) * 2 * C;
     const int c = final_sums(partial, nblocks, C, sb, sg);
     if (c < 0) return;
-    dbeta[c] = sb;
-    dgamma[c] = sg;
+    const long o = blockIdx.y * ostride + c;
+    if (out_bf16) {
+        static_cast<bf16*>(dbeta)[o] = f2bf(sb);
+        static_cast<bf16*>(dgamma)[o] = f2bf(sg);
+    } else {
+        static_cast<float*>(dbeta)[o] = sb;
+        static_cast<float*>(dgamma)[o] = sg;
+    }
     coef[c] = sb * inv_count;
     coef[C + c] = sg * inv_count;
 }
 
 template <bool kRelu, bool kRes>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16* dy, const bf16* y,
-                                                           const bf16* x, const float* stats,
-                                                           const float* coef, const float* gamma,
-                                                           bf16* dx, bf16* dres, long n8, int C) {
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16* dy, const bf16* dy2,
+                                                           const bf16* y, const bf16* x,
+                                                           const float* stats, const float* coef,
+                                                           const float* gamma, bf16* dx,
+                                                           bf16* dres, long n8, int C,
+                                                           long pstride) {
+    {
+        const long gofs = static_cast<long>(blockIdx.y) * n8 * 8;
+        dy += gofs;
+        if (dy2 != nullptr) dy2 += gofs;
+        x += gofs;
+        dx += gofs;
+        if (kRelu) y += gofs;
+        if (kRes) dres += gofs;
+        stats += static_cast<long>(blockIdx.y) * 2 * C;
+        coef += static_cast<long>(blockIdx.y) * 2 * C;
+        gamma += blockIdx.y * pstride;
+    }
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
          i += static_cast<long>(gridDim.x) * 256) {
         const int c0 = static_cast<int>((i * 8) % C);
         float d[8], xv[8], o[8];
-        load8(dy + i * 8, d);
+        load_dy(dy, dy2, i * 8, d);
         load8(x + i * 8, xv);
         if (kRelu) {
             float yv[8];
@@ -268,6 +338,83 @@ inline int grid_cap(long n8) {
     return static_cast<int>(b);
 }
 
+int bn_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+               float* running_mean, float* running_var, float* stats, float* workspace, int G,
+               long R, int C, int relu, float momentum, float eps, int pre_blocks, long pstride,
+               hipStream_t s) {
+    const int lpr = lanes_per_row(C);
+    if (lpr == 0 || R <= 0 || pre_blocks < 0 || G < 1 || G > 65535) return -1;
+    if (!al16(x) || !al16(y) || (res != nullptr && !al16(res))) return -2;
+    if (G > 1 && (R * C) % 8 != 0) return -3;
+    int nb = pre_blocks;
+    if (pre_blocks == 0) {
+        nb = blocks_for(R, lpr);
+        const long rpb = (R + nb - 1) / nb;
+        const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb, G), dim3(256), lds, s,
+                           static_cast<const bf16*>(x), workspace, R, C, lpr, rpb);
+    }
+    const float unbias = R > 1 ? static_cast<float>(R) / static_cast<float>(R - 1) : 1.f;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s, workspace,
+                       stats, running_mean, running_var, nb, C, 1.f / static_cast<float>(R),
+                       unbias, momentum, eps, pstride);
+    const long n8 = R * C / 8;
+    const dim3 grid(grid_cap(n8), G), block(256);
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* rp = static_cast<const bf16*>(res);
+    bf16* yp = static_cast<bf16*>(y);
+    if (relu && res != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, pstride);
+    else if (relu)
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, pstride);
+    else if (res != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, pstride);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, pstride);
+    return static_cast<int>(hipGetLastError());
+}
+
+int bn_backward(const void* dy, const void* dy2, const void* y, const void* x, const float* stats,
+                const float* gamma, void* dx, void* dres, void* dgamma, void* dbeta,
+                float* workspace, int G, long R, int C, int relu, long pstride, int out_bf16,
+                long ostride, hipStream_t s) {
+    const int lpr = lanes_per_row(C);
+    if (lpr == 0 || R <= 0 || G < 1 || G > 65535) return -1;
+    if (!al16(dy) || !al16(x) || !al16(dx) || (relu && !al16(y)) ||
+        (dres != nullptr && !al16(dres)) || (dy2 != nullptr && !al16(dy2)))
+        return -2;
+    if (G > 1 && (R * C) % 8 != 0) return -3;
+    const int nb = blocks_for(R, lpr);
+    const long rpb = (R + nb - 1) / nb;
+    const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
+    float* coef = workspace + static_cast<long>(G) * kMaxBlocks * 2 * C;
+    const bf16* dyp = static_cast<const bf16*>(dy);
+    const bf16* dy2p = static_cast<const bf16*>(dy2);
+    const bf16* yp = static_cast<const bf16*>(y);
+    const bf16* xp = static_cast<const bf16*>(x);
+    if (relu)
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nb, G), dim3(256), lds, s, dyp, dy2p,
+                           yp, xp, stats, workspace, R, C, lpr, rpb);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nb, G), dim3(256), lds, s, dyp, dy2p,
+                           yp, xp, stats, workspace, R, C, lpr, rpb);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s, workspace, coef,
+                       dgamma, dbeta, nb, C, 1.f / static_cast<float>(R), out_bf16, ostride);
+    const long n8 = R * C / 8;
+    const dim3 grid(grid_cap(n8), G), block(256);
+    bf16* dxp = static_cast<bf16*>(dx);
+    bf16* drp = static_cast<bf16*>(dres);
+    if (relu && dres != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, block, 0, s, dyp, dy2p, yp, xp, stats, coef, gamma, dxp, drp, n8, C, pstride);
+    else if (relu)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, block, 0, s, dyp, dy2p, yp, xp, stats, coef, gamma, dxp, drp, n8, C, pstride);
+    else if (dres != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, block, 0, s, dyp, dy2p, yp, xp, stats, coef, gamma, dxp, drp, n8, C, pstride);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, block, 0, s, dyp, dy2p, yp, xp, stats, coef, gamma, dxp, drp, n8, C, pstride);
+    return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,6 +422,7 @@ extern "C" {
 // 1 when the channel count is supported (C/8 a power of two in [8, 64]).
 int nf_bn_supported(int C) { return lanes_per_row(C) != 0; }
 
+// floats of workspace per group (the backward pass needs 2 * C more per group)
 int nf_bn_workspace_floats(int C) { return kMaxBlocks * 2 * C; }
 
 // stats: 2*C floats (mean, 1/std) kept for the backward pass.  running_* may
@@ -285,35 +433,8 @@ int nf_bn_workspace_floats(int C) { return kMaxBlocks * 2 * C; }
 int nf_bn_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
               float* running_mean, float* running_var, float* stats, float* workspace, long R,
               int C, int relu, float momentum, float eps, int pre_blocks, hipStream_t s) {
-    const int lpr = lanes_per_row(C);
-    if (lpr == 0 || R <= 0 || pre_blocks < 0) return -1;
-    if (!al16(x) || !al16(y) || (res != nullptr && !al16(res))) return -2;
-    int nb = pre_blocks;
-    if (pre_blocks == 0) {
-        nb = blocks_for(R, lpr);
-        const long rpb = (R + nb - 1) / nb;
-        const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
-        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), lds, s,
-                           static_cast<const bf16*>(x), workspace, R, C, lpr, rpb);
-    }
-    const float unbias = R > 1 ? static_cast<float>(R) / static_cast<float>(R - 1) : 1.f;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace,
-                       stats, running_mean, running_var, nb, C, 1.f / static_cast<float>(R),
-                       unbias, momentum, eps);
-    const long n8 = R * C / 8;
-    const dim3 grid(grid_cap(n8)), block(256);
-    const bf16* xp = static_cast<const bf16*>(x);
-    const bf16* rp = static_cast<const bf16*>(res);
-    bf16* yp = static_cast<bf16*>(y);
-    if (relu && res != nullptr)
-        hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
-    else if (relu)
-        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
-    else if (res != nullptr)
-        hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
-    else
-        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C);
-    return static_cast<int>(hipGetLastError());
+    return bn_forward(x, res, y, gamma, beta, running_mean, running_var, stats, workspace, 1, R,
+                      C, relu, momentum, eps, pre_blocks, 0, s);
 }
 
 // dgamma / dbeta (fp32) are overwritten.  dres (may be null) receives the
@@ -321,38 +442,32 @@ int nf_bn_fwd(const void* x, const void* res, void* y, const float* gamma, const
 int nf_bn_bwd(const void* dy, const void* y, const void* x, const float* stats,
               const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta,
               float* workspace, long R, int C, int relu, hipStream_t s) {
-    const int lpr = lanes_per_row(C);
-    if (lpr == 0 || R <= 0) return -1;
-    if (!al16(dy) || !al16(x) || !al16(dx) || (relu && !al16(y)) || (dres != nullptr && !al16(dres)))
-        return -2;
-    const int nb = blocks_for(R, lpr);
-    const long rpb = (R + nb - 1) / nb;
-    const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
-    float* coef = workspace + static_cast<long>(kMaxBlocks) * 2 * C;
-    const bf16* dyp = static_cast<const bf16*>(dy);
-    const bf16* yp = static_cast<const bf16*>(y);
-    const bf16* xp = static_cast<const bf16*>(x);
-    if (relu)
-        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nb), dim3(256), lds, s, dyp, yp, xp,
-                           stats, workspace, R, C, lpr, rpb);
-    else
-        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nb), dim3(256), lds, s, dyp, yp, xp,
-                           stats, workspace, R, C, lpr, rpb);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace, coef,
-                       dgamma, dbeta, nb, C, 1.f / static_cast<float>(R));
-    const long n8 = R * C / 8;
-    const dim3 grid(grid_cap(n8)), block(256);
-    bf16* dxp = static_cast<bf16*>(dx);
-    bf16* drp = static_cast<bf16*>(dres);
-    if (relu && dres != nullptr)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
-    else if (relu)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
-    else if (dres != nullptr)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, block, 0, s, dyp, yp, xp, stats, coef, gamma, dxp, drp, n8, C);
-    return static_cast<int>(hipGetLastError());
+    return bn_backward(dy, nullptr, y, x, stats, gamma, dx, dres, dgamma, dbeta, workspace, 1, R,
+                       C, relu, 0, 0, 0, s);
+}
+
+// G independent batches of R rows, stored one after the other in x / res / y.
+// gamma, beta, running_mean, running_var: group 0's vectors; group g's start pstride
+// floats later.  stats: [G][2][C].  workspace: G * nf_bn_workspace_floats(C) floats;
+// with pre_blocks > 0 it holds [G][pre_blocks][2][C] partial sums.
+int nf_bn_fwd_g(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float* stats, float* workspace, int G,
+                long R, int C, int relu, float momentum, float eps, int pre_blocks, long pstride,
+                hipStream_t s) {
+    if (pre_blocks > kMaxBlocks * 64) return -1;
+    return bn_forward(x, res, y, gamma, beta, running_mean, running_var, stats, workspace, G, R,
+                      C, relu, momentum, eps, pre_blocks, pstride, s);
+}
+
+// Grouped backward.  dy2 (may be null): second addend of the incoming gradient.
+// dgamma / dbeta: group 0's output vectors, fp32 or (out_bf16) bf16, group g's ostride
+// elements later.  workspace: G * (nf_bn_workspace_floats(C) + 2 * C) floats.
+int nf_bn_bwd_g(const void* dy, const void* dy2, const void* y, const void* x,
+                const float* stats, const float* gamma, void* dx, void* dres, void* dgamma,
+                void* dbeta, float* workspace, int G, long R, int C, int relu, long pstride,
+                int out_bf16, long ostride, hipStream_t s) {
+    return bn_backward(dy, dy2, y, x, stats, gamma, dx, dres, dgamma, dbeta, workspace, G, R, C,
+                       relu, pstride, out_bf16, ostride, s);
 }
 
 }  // extern "C"

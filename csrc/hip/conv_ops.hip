@@ -27,6 +27,12 @@
 // nine MFMAs).  Pixel ranges write partial slabs (bf16: the kernel is bound by
 // this traffic, and the sum itself is bf16) that a second kernel sums in fp32 in a
 // fixed order (no atomics: results do not depend on scheduling).
+//
+// Grouped launches (the *_g entry points): the batch holds G groups of B images, one
+// after the other - the clients that share a GPU, each with weights of its own.  Group
+// g's weights start `w_stride` elements after those of group g - 1 (rows of a parameter
+// arena); a pixel tile never spans two groups, so a workgroup picks its weights from its
+// tile index.  The weight gradient sums each group's pixel ranges separately.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -63,6 +69,8 @@ struct ConvGeo {
     int NI;                // bands per tile
     int np;                // patch pixels of a tile: NI * (RI + 2) * (W + 2)
     int Cin, Cout;
+    int tpg;               // pixel tiles per group (of the launch's tile size)
+    long wgs;              // weight elements between consecutive groups
 };
 
 // Patch pixel pp of the tile whose first image row (index over b * H + y) is row0:
@@ -100,6 +108,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
     const int PW = g.W + 2;
     const int row0 = (tile * TP) >> g.logW;
+    w += (tile / g.tpg) * g.wgs;  // this group's weights
 
     // staging plan of the activation patch: pieces tid + 256 i, 16 bytes each
     int a_src[kMaxAPieces], a_dst[kMaxAPieces];
@@ -435,8 +444,11 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
 // consecutive elements; its four waves each sum every fourth slab (so that few,
 // long columns still spread over the chip) and combine through LDS.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const bf16* __restrict__ part, bf16* __restrict__ dw, long n4, int slabs) {
+wgrad_reduce_kernel(const bf16* __restrict__ part, bf16* __restrict__ dw, long n4, int slabs,
+                    long dw_stride) {
     __shared__ float4 red[3][64];
+    part += static_cast<long>(blockIdx.y) * slabs * n4 * 4;  // blockIdx.y: group
+    dw += blockIdx.y * dw_stride;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long i = static_cast<long>(blockIdx.x) * 64 + lane;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -485,6 +497,8 @@ bool make_geo(int B, int H, int W, int Cin, int Cout, int tp, int max_patch, Con
     g->NI = rows / g->RI;
     g->np = g->NI * (g->RI + 2) * (W + 2);
     g->Cin = Cin; g->Cout = Cout;
+    g->tpg = static_cast<int>(M / tp);
+    g->wgs = 0;
     return g->np <= max_patch;
 }
 
@@ -511,22 +525,27 @@ inline int set_lds(const void* fn, int bytes) {
 
 // pixel ranges of the weight gradient: as few slabs as keep g_wgrad_min_wgs
 // workgroups in flight, at least one iteration of 128 pixels each
-int wgrad_iterations(long M, int Cin, int Cout) {
-    const long tiles = static_cast<long>(Cin / 64) * (Cout / 64);
-    const long iters = M / kWgTP;
+int wgrad_iterations(long M, int Cin, int Cout, int G = 1) {
+    const long tiles = static_cast<long>(Cin / 64) * (Cout / 64) * G;
+    const long iters = M / kWgTP;  // per group
     long nit = 1;
     while (nit * 2 <= iters && (iters / (nit * 2)) * tiles >= g_wgrad_min_wgs && iters % (nit * 2) == 0) nit *= 2;
     return static_cast<int>(nit);
 }
 
+// B: images of the whole launch (all groups), G groups of B / G images
 template <bool kDgrad>
 int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int H, int W,
-               int Cin, int Cout, hipStream_t s) {
+               int Cin, int Cout, hipStream_t s, int G = 1, long w_stride = 0) {
+    if (G < 1 || B % G != 0) return -1;
     const int tp = fwd_tile_pixels(B, H, W, Cout);
     ConvGeo g;
     if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
     if (!al16(x) || !al16(w) || !al16(y)) return -2;
     const long M = static_cast<long>(B) * H * W;
+    if ((M / G) % tp != 0 || (w_stride & 7) != 0) return -3;
+    g.tpg = static_cast<int>(M / G / tp);
+    g.wgs = w_stride;
     const dim3 grid(static_cast<unsigned>(M / tp), Cout / 64);
     const bf16* xp = static_cast<const bf16*>(x);
     const bf16* wp = static_cast<const bf16*>(w);
@@ -600,6 +619,39 @@ int nf_conv3x3_flip_weights(const void* w, void* wt, int Cin, int Cout, hipStrea
 // make this many workgroups (default 192).
 void nf_conv3x3_set_wgrad_min_workgroups(int n) { g_wgrad_min_wgs = n < 1 ? 1 : n; }
 
+}  // extern "C"
+
+namespace {
+
+// weight gradient of G groups of B / G images each; dw of group g starts dw_stride
+// elements after that of group g - 1
+int wgrad_launch(const void* x, const void* dy, void* dw, void* workspace, int B, int H, int W,
+                 int Cin, int Cout, int G, long dw_stride, hipStream_t s) {
+    ConvGeo g;
+    if (G < 1 || B % G != 0) return -1;
+    if (!make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g)) return -1;
+    if (!al16(x) || !al16(dy) || !al16(dw) || !al16(workspace) || (dw_stride & 7) != 0) return -2;
+    const long Mg = static_cast<long>(B / G) * H * W;
+    if (Mg % kWgTP != 0) return -3;
+    const int nit = wgrad_iterations(Mg, Cin, Cout, G);
+    const int slabs = static_cast<int>(Mg / kWgTP / nit);  // per group
+    const dim3 grid(slabs * G, (Cout / 64) * (Cin / 64));
+    static const int lds_ok = set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), kWgLds);
+    if (lds_ok != 0) return -20;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), kWgLds, s,
+                       static_cast<const bf16*>(x), static_cast<const bf16*>(dy),
+                       static_cast<bf16*>(workspace), g, nit);
+    const long n4 = static_cast<long>(Cout) * 9 * Cin / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((n4 + 63) / 64), G),
+                       dim3(256), 0, s, static_cast<const bf16*>(workspace), static_cast<bf16*>(dw),
+                       n4, slabs, dw_stride);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
 // bf16 elements of workspace nf_conv3x3_wgrad needs
 long nf_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
     const long M = static_cast<long>(B) * H * W;
@@ -611,23 +663,45 @@ long nf_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
 // dw[Cout][3][3][Cin] (bf16) = weight gradient of the convolution above.
 int nf_conv3x3_wgrad(const void* x, const void* dy, void* dw, void* workspace, int B, int H,
                      int W, int Cin, int Cout, hipStream_t s) {
+    return wgrad_launch(x, dy, dw, workspace, B, H, W, Cin, Cout, 1, 0, s);
+}
+
+// -- grouped launches: G groups of B images each (G * B images in x / y / dy) ----------
+
+int nf_conv3x3_supported_g(int G, int B, int H, int W, int Cin, int Cout) {
+    if (G < 1 || B < 1) return 0;
     ConvGeo g;
-    if (!make_geo(B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g)) return -1;
-    if (!al16(x) || !al16(dy) || !al16(dw) || !al16(workspace)) return -2;
-    const long M = static_cast<long>(B) * H * W;
-    const int nit = wgrad_iterations(M, Cin, Cout);
-    const int slabs = static_cast<int>(M / kWgTP / nit);
-    const dim3 grid(slabs, (Cout / 64) * (Cin / 64));
-    static const int lds_ok = set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), kWgLds);
-    if (lds_ok != 0) return -20;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), kWgLds, s,
-                       static_cast<const bf16*>(x), static_cast<const bf16*>(dy),
-                       static_cast<bf16*>(workspace), g, nit);
-    const long n4 = static_cast<long>(Cout) * 9 * Cin / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((n4 + 63) / 64)),
-                       dim3(256), 0, s, static_cast<const bf16*>(workspace), static_cast<bf16*>(dw),
-                       n4, slabs);
-    return static_cast<int>(hipGetLastError());
+    const long Mg = static_cast<long>(B) * H * W;
+    if (!fwd_geo(G * B, H, W, Cin, Cout, &g) || Mg % fwd_tile_pixels(G * B, H, W, Cout) != 0) return 0;
+    if (!fwd_geo(G * B, H, W, Cout, Cin, &g) || Mg % fwd_tile_pixels(G * B, H, W, Cin) != 0) return 0;
+    return make_geo(G * B, H, W, Cin, Cout, kWgTP, kWgMaxPatch, &g) && Mg % kWgTP == 0 ? 1 : 0;
+}
+
+// pixel tiles per group of the grouped forward launch (rows of colsum per group)
+int nf_conv3x3_fwd_tiles_g(int G, int B, int H, int W, int Cout) {
+    return static_cast<int>(static_cast<long>(B) * H * W / fwd_tile_pixels(G * B, H, W, Cout));
+}
+
+int nf_conv3x3_fwd_g(const void* x, const void* w, void* y, float* colsum, int G, int B, int H,
+                     int W, int Cin, int Cout, long w_stride, hipStream_t s) {
+    return launch_fwd<false>(x, w, y, colsum, G * B, H, W, Cin, Cout, s, G, w_stride);
+}
+
+int nf_conv3x3_dgrad_g(const void* dy, const void* w, void* dx, int G, int B, int H, int W,
+                       int Cin, int Cout, long w_stride, hipStream_t s) {
+    return launch_fwd<true>(dy, w, dx, nullptr, G * B, H, W, Cout, Cin, s, G, w_stride);
+}
+
+long nf_conv3x3_wgrad_workspace_g(int G, int B, int H, int W, int Cin, int Cout) {
+    const long Mg = static_cast<long>(B) * H * W;
+    if (G < 1 || Mg % kWgTP != 0 || Cin % 64 != 0 || Cout % 64 != 0) return -1;
+    const int nit = wgrad_iterations(Mg, Cin, Cout, G);
+    return G * (Mg / kWgTP / nit) * static_cast<long>(Cout) * 9 * Cin;
+}
+
+int nf_conv3x3_wgrad_g(const void* x, const void* dy, void* dw, void* workspace, int G, int B,
+                       int H, int W, int Cin, int Cout, long dw_stride, hipStream_t s) {
+    return wgrad_launch(x, dy, dw, workspace, G * B, H, W, Cin, Cout, G, dw_stride, s);
 }
 
 }  // extern "C"

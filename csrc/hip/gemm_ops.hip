@@ -74,6 +74,7 @@ struct GemmArgs {
     int M, N, K;
     int splits;       // 1 = plain mode
     int tiles_m, tiles_n;
+    long sA, sB, sC;  // batched launches: elements between consecutive problems (blockIdx.z)
 };
 
 // tanh-GELU, the arithmetic of gelu_fwd_kernel in nn_ops.hip (same bits)
@@ -162,6 +163,10 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     int tm, tn;
     tile_of(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    // batched launch: problem blockIdx.z of gridDim.z equally shaped ones
+    g.A += blockIdx.z * g.sA;
+    g.B += blockIdx.z * g.sB;
+    g.C += blockIdx.z * g.sC;
 
     // K range of this workgroup (split-K: contiguous ranges of whole K steps); only
     // the very last step of the matrix can be partial
@@ -389,7 +394,7 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     const int wrow = wm * (BM / G::WM), wcol = wn * (BN / G::WN);
     if (g.splits > 1) {
         // fp32 slab of this K range: row segments of 32 columns per half wave
-        float* slab = g.slabs + static_cast<long>(blockIdx.y) * g.M * g.N;
+        float* slab = g.slabs + (static_cast<long>(blockIdx.z) * g.splits + blockIdx.y) * g.M * g.N;
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -456,8 +461,10 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restric
                                                           bf16* __restrict__ out,
                                                           bf16* __restrict__ out2,
                                                           const bf16* __restrict__ bias, long ldc,
-                                                          int M, int N, int splits) {
+                                                          int M, int N, int splits, long sC) {
     const long total = static_cast<long>(M) * N;
+    slabs += static_cast<long>(blockIdx.y) * splits * total;  // blockIdx.y: problem of a batch
+    out += blockIdx.y * sC;
     const long stride = static_cast<long>(gridDim.x) * blockDim.x;
     if ((N & 3) == 0) {
         const long total4 = total >> 2;
@@ -505,27 +512,27 @@ using Geo128x192 = Geo<128, 192, 4, 2>;  // 32 x 96 per wave, 2 stages of 40 KiB
                                          // rows of a multiple of 256 bytes)
 
 template <class G, bool A_KM, bool B_KM>
-int launch(GemmArgs g, hipStream_t stream) {
+int launch(GemmArgs g, int batch, hipStream_t stream) {
     static const hipError_t lds_ok = hipFuncSetAttribute(
         reinterpret_cast<const void*>(gemm_kernel<G, A_KM, B_KM>),
         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (lds_ok != hipSuccess) return -20;
     g.tiles_m = (g.M + G::BM - 1) / G::BM;
     g.tiles_n = (g.N + G::BN - 1) / G::BN;
-    hipLaunchKernelGGL((gemm_kernel<G, A_KM, B_KM>), dim3(g.tiles_m * g.tiles_n, g.splits),
+    hipLaunchKernelGGL((gemm_kernel<G, A_KM, B_KM>), dim3(g.tiles_m * g.tiles_n, g.splits, batch),
                        dim3(kThreads), G::LDS, stream, g);
     return static_cast<int>(hipGetLastError());
 }
 
 template <bool A_KM, bool B_KM>
-int launch_geo(int geo, const GemmArgs& g, hipStream_t stream) {
+int launch_geo(int geo, const GemmArgs& g, int batch, hipStream_t stream) {
     switch (geo) {
-    case 0: return launch<Geo128, A_KM, B_KM>(g, stream);
-    case 1: return launch<Geo256x128, A_KM, B_KM>(g, stream);
-    case 2: return launch<Geo256, A_KM, B_KM>(g, stream);
-    case 3: return launch<Geo128x2, A_KM, B_KM>(g, stream);
+    case 0: return launch<Geo128, A_KM, B_KM>(g, batch, stream);
+    case 1: return launch<Geo256x128, A_KM, B_KM>(g, batch, stream);
+    case 2: return launch<Geo256, A_KM, B_KM>(g, batch, stream);
+    case 3: return launch<Geo128x2, A_KM, B_KM>(g, batch, stream);
     case 4:
-        if constexpr (!A_KM && !B_KM) return launch<Geo128x192, false, false>(g, stream);
+        if constexpr (!A_KM && !B_KM) return launch<Geo128x192, false, false>(g, batch, stream);
         else return -7;
     default: return -7;
     }
@@ -538,18 +545,22 @@ extern "C" {
 int nf_gemm_geometries() { return 5; }
 
 // layout: 0 = NT (A [M][K], B [N][K]), 1 = NN (A [M][K], B [K][N]), 2 = TN (A [K][M], B [K][N]).
-// splits > 1: `slabs` must hold splits * M * N floats; the bf16 result is written to C
+// splits > 1: `slabs` must hold batch * splits * M * N floats; the bf16 result is written to C
 // by a second launch, which also applies bias / C2.  bias / C2 may be null.
-// geo: workgroup tile, 0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256.
-int nf_gemm_bf16(int layout, int geo, const void* A, const void* B, void* C, void* C2,
-                 const void* bias, float* slabs, int M, int N, int K, long lda, long ldb, long ldc,
-                 int splits, hipStream_t stream) {
-    if (M < 1 || N < 1 || K < 1 || splits < 1 || splits > 64) return -1;
+// geo: workgroup tile, see nf_gemm_geometries.
+// batch > 1: that many problems of one shape in one launch; problem b reads A + b sA,
+// B + b sB and writes C + b sC (elements; multiples of 8).  No bias / C2 then.
+int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void* C, void* C2,
+                         const void* bias, float* slabs, int M, int N, int K, long lda, long ldb,
+                         long ldc, int splits, int batch, long sA, long sB, long sC,
+                         hipStream_t stream) {
+    if (M < 1 || N < 1 || K < 1 || splits < 1 || splits > 64 || batch < 1 || batch > 65535) return -1;
     if ((lda & 7) || (ldb & 7) || (ldc & 7)) return -2;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) |
          reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(C2)) & 15)
         return -3;
     if (splits > 1 && slabs == nullptr) return -4;
+    if (batch > 1 && (C2 != nullptr || bias != nullptr || ((sA | sB | sC) & 7) != 0)) return -9;
     // leading dimensions must cover the rows the kernel reads (16-byte pieces)
     const long need_a = layout == 2 ? ((M + 7) & ~7) : ((K + 7) & ~7);
     const long need_b = layout == 0 ? ((K + 7) & ~7) : ((N + 7) & ~7);
@@ -568,11 +579,12 @@ int nf_gemm_bf16(int layout, int geo, const void* A, const void* B, void* C, voi
     g.M = M; g.N = N; g.K = K;
     g.splits = splits;
     g.tiles_m = g.tiles_n = 0;
+    g.sA = batch > 1 ? sA : 0; g.sB = batch > 1 ? sB : 0; g.sC = batch > 1 ? sC : 0;
     int rc;
     switch (layout) {
-    case 0: rc = launch_geo<false, false>(geo, g, stream); break;
-    case 1: rc = launch_geo<false, true>(geo, g, stream); break;
-    case 2: rc = launch_geo<true, true>(geo, g, stream); break;
+    case 0: rc = launch_geo<false, false>(geo, g, batch, stream); break;
+    case 1: rc = launch_geo<false, true>(geo, g, batch, stream); break;
+    case 2: rc = launch_geo<true, true>(geo, g, batch, stream); break;
     default: return -6;
     }
     if (rc) return rc;
@@ -581,12 +593,19 @@ int nf_gemm_bf16(int layout, int geo, const void* A, const void* B, void* C, voi
         long blocks = (total / 4 + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                           stream, slabs, static_cast<bf16*>(C), static_cast<bf16*>(C2),
-                           static_cast<const bf16*>(bias), ldc, M, N, splits);
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3(static_cast<unsigned>(blocks), batch), dim3(256),
+                           0, stream, slabs, static_cast<bf16*>(C), static_cast<bf16*>(C2),
+                           static_cast<const bf16*>(bias), ldc, M, N, splits, g.sC);
         return static_cast<int>(hipGetLastError());
     }
     return 0;
+}
+
+int nf_gemm_bf16(int layout, int geo, const void* A, const void* B, void* C, void* C2,
+                 const void* bias, float* slabs, int M, int N, int K, long lda, long ldb, long ldc,
+                 int splits, hipStream_t stream) {
+    return nf_gemm_bf16_batched(layout, geo, A, B, C, C2, bias, slabs, M, N, K, lda, ldb, ldc,
+                                splits, 1, 0, 0, 0, stream);
 }
 
 }  // extern "C"

@@ -347,6 +347,13 @@ class FederatedEngine:
             from .gpt2_native import GPT2NativeTrainer
 
             return GPT2NativeTrainer(cfg, self.pool, self.shards, self.data, self._host_model.cfg)
+        if self.backend == "native" and cfg.model == "resnet18":
+            from .resnet_native import ResNetNativeTrainer
+
+            return ResNetNativeTrainer(
+                cfg, self.pool, self.shards, self._model_factory,
+                self.data.eval_inputs, self.data.eval_labels,
+            )
         if self.backend == "native":
             raise DeviceError(f"no native trainer for model {cfg.model!r}")
         return TorchGroupTrainer(
@@ -371,7 +378,12 @@ class FederatedEngine:
                 m.n_embd == 64 * m.n_head and m.dropout == 0.0 and cfg.seq_len % 128 == 0
                 and m.n_embd <= 2048
             )
-        return "native" if (mnist_ok or gpt2_ok) else "torch"
+        resnet_ok = False
+        if cfg.model == "resnet18" and on_gpu:
+            from .resnet_native import supports as resnet_supports
+
+            resnet_ok = resnet_supports(cfg, self._host_model, self.device)
+        return "native" if (mnist_ok or gpt2_ok or resnet_ok) else "torch"
 
     def _setup_persistence(self) -> None:
         from nanofed_amd.server.model_manager import ModelManager

@@ -53,6 +53,12 @@ def _check(t: torch.Tensor, name: str) -> None:
 
 
 def _slab_buffer(dev: torch.device, floats: int) -> torch.Tensor:
+    """fp32 scratch of a split-K launch.  Eager launches reuse one buffer per stream.
+    A launch that is being captured into a graph gets a buffer of its own from the
+    graph's memory pool: graphs captured one after the other on the same stream may
+    later be replayed concurrently on different streams, and must not share scratch."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(floats, dtype=torch.float32, device=dev)
     key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
     buf = _slabs.get(key)
     if buf is None or buf.numel() < floats:
@@ -68,17 +74,18 @@ _GEO_TILE = {GEO_128: (128, 128), GEO_256x128: (256, 128), GEO_256: (256, 256),
 _FORCED_GEO = os.environ.get("NANOFED_GEMM_GEO")
 
 
-def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0) -> int:
+def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1) -> int:
     """Workgroup tile for an ``M x N`` output with reduction length ``K``.  Bigger
     tiles load fewer operand bytes per MFMA but make fewer workgroups and need a
     long K loop to pay for their prologue; the 128 x 128 tile with two LDS stages lets
     two workgroups share a compute unit, so one's prologue and epilogue overlap the
     other's main loop - the best choice at the GPT-2-small layer shapes in all three
-    layouts.  The thresholds are read off ``tools/bench_gemm.py --geometries``."""
+    layouts.  The thresholds are read off ``tools/bench_gemm.py --geometries``.
+    ``batch``: equally shaped problems that share the launch (their tiles add up)."""
     if _FORCED_GEO is not None:
         return int(_FORCED_GEO)
     ksteps = (K + 63) // 64
-    t256 = (-(-M // 256)) * (-(-N // 256))
+    t256 = (-(-M // 256)) * (-(-N // 256)) * batch
     if t256 >= 224 and ksteps >= 32 and min(M, N) >= 2048:
         return GEO_256        # enough 256 x 256 tiles for every CU, a long K loop, both sides wide
     if t256 >= 1024 and layout == NT:
@@ -86,8 +93,8 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0) -> int:
     if layout == NT and N % 192 == 0:
         # k-contiguous operands may use 128 x 192 tiles: when they make about one full
         # round of workgroups (two per CU) where 128 x 128 tiles make one and a half
-        t192 = (-(-M // 128)) * (N // 192)
-        t128 = (-(-M // 128)) * (-(-N // 128))
+        t192 = (-(-M // 128)) * (N // 192) * batch
+        t128 = (-(-M // 128)) * (-(-N // 128)) * batch
         if 256 <= t192 <= 512 < t128:
             return GEO_128x192
     return GEO_128_2
@@ -161,7 +168,7 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
     out.copy_((dy.float() @ w.float()).to(torch.bfloat16))
 
 
-def choose_splits(M: int, N: int, K: int, geo: int = GEO_128) -> int:
+def choose_splits(M: int, N: int, K: int, geo: int = GEO_128, batch: int = 1) -> int:
     """Split factor of a GEMM with ``M x N`` outputs and reduction length ``K``.  A
     launch with fewer tiles than the chip has workgroup slots is cut along K until tiles
     times ranges come to about 430 workgroups (two per CU, a little under two full
@@ -170,7 +177,7 @@ def choose_splits(M: int, N: int, K: int, geo: int = GEO_128) -> int:
     of small layers: K is the number of pixels or tokens) have almost no slab traffic:
     they are cut into ranges as short as 4 steps, up to 64."""
     bm, bn = _GEO_TILE[geo]
-    tiles = (-(-M // bm)) * (-(-N // bn))
+    tiles = (-(-M // bm)) * (-(-N // bn)) * batch
     if tiles >= 200:
         return 1
     ksteps = (K + 63) // 64

@@ -86,3 +86,26 @@ def test_resnet_streams_count_batchnorm_steps():
     for p, _ in tr._leaves[0]:
         assert p.grad is None
         assert p.dtype == (torch.bfloat16 if p.dim() >= 2 else torch.float32)
+
+
+def test_resnet_graphs_replayed_on_concurrent_streams_share_no_scratch():
+    """Every client's step graph is captured on the main stream and replayed on the
+    client's stream, four at a time.  Scratch memory that two graphs shared (the split-K
+    buffer of the convolution GEMMs once did) would be overwritten by a neighbour: the
+    run on streams must give the model of the run that trains client after client."""
+    kw = dict(model="resnet18", dataset="synthetic_cifar10", backend="torch", num_clients=4,
+              local_epochs=1, batch_size=32, samples_per_client=128, eval_samples=64,
+              learning_rate=0.05, seed=4)
+    outs = []
+    for streams in (False, True):
+        torch.cuda.set_device(0)
+        eng = FederatedEngine(EngineConfig(client_streams=streams, **kw),
+                              comm=Communicator(device=torch.device("cuda", 0)))
+        reps = eng.run(2)
+        assert (eng.trainer._streams is not None) == streams
+        assert len(eng.trainer._graphs) == 4
+        outs.append((eng.global_arena.data.float().cpu(), reps[-1].agg_metrics["loss"]))
+    (a, la), (b, lb) = outs
+    rel = float((a - b).norm() / a.norm())
+    assert rel < 1e-3, rel
+    assert lb == pytest.approx(la, rel=1e-2)

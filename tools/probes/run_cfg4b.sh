@@ -1,0 +1,5 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 300 python -u -m pytest tests/gpu/test_torch_trainer_graph.py tests/gpu/test_conv_gemm_gpu.py tests/gpu/test_gemm_kernels.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -8 || exit 1
+echo "== per-client trainer"; NANOFED_RESNET_NATIVE=0 timeout -k 10 280 python -u benchmarks/run_configs.py resnet18 --rounds 5 --warmup 2 2> gpurun_out/cfg4_perclient.err | tee gpurun_out/cfg4_perclient.json || { tail -20 gpurun_out/cfg4_perclient.err; exit 1; }
