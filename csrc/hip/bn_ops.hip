@@ -152,6 +152,9 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* partia
     }
 }
 
+// A thread keeps the 8 channels of its first piece for the whole loop (the stride of the
+// loop, 8 * 256 * gridDim.x elements, is a multiple of C), so the per-channel factors
+// are loaded once and every piece costs one 16-byte load per operand, 8 FMAs and one store.
 template <bool kRelu, bool kRes>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16* x, const bf16* res,
                                                        const float* stats, const float* gamma,
@@ -166,16 +169,19 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16* x, const bf16
         gamma += blockIdx.y * pstride;
         beta += blockIdx.y * pstride;
     }
-    for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
-         i += static_cast<long>(gridDim.x) * 256) {
-        const int c0 = static_cast<int>((i * 8) % C);
+    const long first = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+    const int c0 = static_cast<int>((first * 8) % C);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = stats[C + c0 + k] * gamma[c0 + k];
+        sh[k] = fmaf(-stats[c0 + k], sc[k], beta[c0 + k]);
+    }
+    for (long i = first; i < n8; i += static_cast<long>(gridDim.x) * 256) {
         float v[8], o[8];
         load8(x + i * 8, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float sc = stats[C + c0 + k] * gamma[c0 + k];
-            o[k] = fmaf(v[k] - stats[c0 + k], sc, beta[c0 + k]);
-        }
+        for (int k = 0; k < 8; ++k) o[k] = fmaf(v[k], sc[k], sh[k]);
         if (kRes) {
             float r[8];
             load8(res + i * 8, r);
@@ -272,6 +278,8 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* partial,
     coef[C + c] = sg * inv_count;
 }
 
+// dx = (dz - mean(dz) - xhat mean(dz xhat)) gamma / std, written as dz fa - x fb + fc with
+// per-channel factors the thread computes once (its channels do not change over the loop)
 template <bool kRelu, bool kRes>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16* dy, const bf16* dy2,
                                                            const bf16* y, const bf16* x,
@@ -291,9 +299,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16* dy, const
         coef += static_cast<long>(blockIdx.y) * 2 * C;
         gamma += blockIdx.y * pstride;
     }
-    for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8;
-         i += static_cast<long>(gridDim.x) * 256) {
-        const int c0 = static_cast<int>((i * 8) % C);
+    const long first = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+    const int c0 = static_cast<int>((first * 8) % C);
+    float fa[8], fb[8], fc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float mu = stats[c0 + k], rs = stats[C + c0 + k];
+        const float k0 = coef[c0 + k], k1 = coef[C + c0 + k];
+        fa[k] = rs * gamma[c0 + k];
+        fb[k] = rs * k1 * fa[k];
+        fc[k] = fmaf(mu, fb[k], -k0 * fa[k]);
+    }
+    for (long i = first; i < n8; i += static_cast<long>(gridDim.x) * 256) {
         float d[8], xv[8], o[8];
         load_dy(dy, dy2, i * 8, d);
         load8(x + i * 8, xv);
@@ -305,11 +322,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16* dy, const
         }
         if (kRes) store8(dres + i * 8, d);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float rs = stats[C + c0 + k];
-            const float xh = (xv[k] - stats[c0 + k]) * rs;
-            o[k] = (d[k] - coef[c0 + k] - xh * coef[C + c0 + k]) * rs * gamma[c0 + k];
-        }
+        for (int k = 0; k < 8; ++k) o[k] = fmaf(d[k], fa[k], fmaf(-xv[k], fb[k], fc[k]));
         store8(dx + i * 8, o);
     }
 }
@@ -331,8 +344,11 @@ inline int blocks_for(long R, int lpr) {
     return static_cast<int>(b);
 }
 
-inline int grid_cap(long n8) {
+// workgroups of an apply pass over n8 pieces per group: about 8 pieces per thread once
+// all groups together fill the chip (>= 1024 workgroups), never more than 2048 per group
+inline int grid_cap(long n8, int G = 1) {
     long b = (n8 + 255) / 256;
+    while (b > 1 && (b / 2) * G >= 1024 && b * 256 * 8 > n8 + 255) b = (b + 1) / 2;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return static_cast<int>(b);
@@ -359,7 +375,7 @@ int bn_forward(const void* x, const void* res, void* y, const float* gamma, cons
                        stats, running_mean, running_var, nb, C, 1.f / static_cast<float>(R),
                        unbias, momentum, eps, pstride);
     const long n8 = R * C / 8;
-    const dim3 grid(grid_cap(n8), G), block(256);
+    const dim3 grid(grid_cap(n8, G), G), block(256);
     const bf16* xp = static_cast<const bf16*>(x);
     const bf16* rp = static_cast<const bf16*>(res);
     bf16* yp = static_cast<bf16*>(y);
@@ -401,7 +417,7 @@ int bn_backward(const void* dy, const void* dy2, const void* y, const void* x, c
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s, workspace, coef,
                        dgamma, dbeta, nb, C, 1.f / static_cast<float>(R), out_bf16, ostride);
     const long n8 = R * C / 8;
-    const dim3 grid(grid_cap(n8), G), block(256);
+    const dim3 grid(grid_cap(n8, G), G), block(256);
     bf16* dxp = static_cast<bf16*>(dx);
     bf16* drp = static_cast<bf16*>(dres);
     if (relu && dres != nullptr)
