@@ -1,8 +1,8 @@
 """Microseconds per 3x3 convolution pass (forward, input gradient, weight
 gradient): the hand-written kernels against the library convolution, for the
-four ResNet-18 stage shapes at batch 64.
+four ResNet-18 stage shapes at batch 64 (or --batch).
 
-    python tools/bench_conv.py [--reps 50] [--min-wgs 192]
+    python tools/bench_conv.py [--reps 50] [--min-wgs 192] [--batch 512]
 """
 
 from __future__ import annotations
@@ -47,6 +47,8 @@ def main() -> None:
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--min-wgs", type=int, default=None)
     ap.add_argument("--no-library", action="store_true")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="images per launch (512 = the eight clients of the grouped ResNet trainer)")
     args = ap.parse_args()
     from nanofed_amd.ops import conv_ops
 
@@ -55,6 +57,7 @@ def main() -> None:
     torch.backends.cudnn.benchmark = True
     out = {}
     for b, h, w, ci, co in SHAPES:
+        b = args.batch
         x = torch.randn(b, ci, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=CL)
         wt = (torch.randn(co, ci, 3, 3, device="cuda") * 0.02).to(torch.bfloat16)
         wt = wt.contiguous(memory_format=CL)
