@@ -4,11 +4,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29521 examples/resnet_cifar/run_federated.py --clients 8
 
-Convolutions run through MIOpen on channels-last arena weights; BatchNorm, the
-residual add and the ReLU are one fused HIP kernel; each client's whole step is
-replayed from a hipGraph; FedAvg is one fused reduce (+ an RCCL all-reduce when
-several GPUs take part).  BatchNorm running statistics are averaged with the
-weights, integer buffers stay out of the float average.
+On a MI355X the engine picks ``ResNetNativeTrainer``: explicit forward and backward on
+hand-written kernels with all clients of the GPU in every launch (implicit-GEMM MFMA
+convolutions, BatchNorm + residual + ReLU, a two-launch head, one SGD launch), the step
+replayed from a hipGraph; FedAvg is one fused reduce (+ an RCCL all-reduce when several
+GPUs take part).  BatchNorm running statistics are averaged with the weights, integer
+buffers stay out of the float average.  ``NANOFED_RESNET_NATIVE=0`` trains client by
+client through autograd instead.
 """
 
 from __future__ import annotations
