@@ -406,9 +406,10 @@ class ResNetNativeTrainer(TorchGroupTrainer):
                 for k in range(G):
                     if full[k] <= s < steps[k]:  # the ragged last batch of client k
                         self._eager_step(k, perms[k][s * B :])
-            for k in range(G):
-                for m in self._bn_layers[k]:
-                    m.num_batches_tracked += steps[k]
+            # BatchNorm step counters (kept in the arena rows, see TorchGroupTrainer)
+            if self._count_idx.numel():
+                add = torch.tensor([float(n) for n in steps], device=self.device)
+                self._arena[:, self._count_idx] += add[:, None]
             del perms, stacked
         batches = self._acc3[:, 2].clamp(min=1.0)
         self.metrics[:, M_SAMPLES] = torch.tensor(
@@ -416,8 +417,6 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         self.metrics[:, M_LOSS] = self._acc3[:, 0] / batches
         self.metrics[:, M_ACC] = self._acc3[:, 1] / batches
         self.metrics[:, M_VALID] = 1.0
-        for k in range(G):
-            self.pool[k].pull_int_buffers(self.modules[k])
         return self.metrics
 
     # -- gradients of one batch per client, without an update (kernel tests) -----------------

@@ -140,14 +140,28 @@ class TorchGroupTrainer(GroupTrainer):
         # BatchNorm layers on the fused kernels leave their step counter to
         # train_round, which bumps it once per epoch instead of once per step
         self._bn_layers: list[list[nn.Module]] = [[] for _ in self.modules]
+        counted: list[str] = []  # their step counters, kept in the arena rows (below)
         if self._channels_last and self._amp:
             from nanofed_amd.ops import bn_ops
 
             for k, module in enumerate(self.modules):
-                for m in module.modules():
+                for name, m in module.named_modules():
                     if isinstance(m, nn.BatchNorm2d) and bn_ops.channels_supported(m.num_features):
                         m.defer_batch_count = True
                         self._bn_layers[k].append(m)
+                        if k == 0 and f"{name}.num_batches_tracked" in pool.layout:
+                            counted.append(f"{name}.num_batches_tracked")
+        # Step counters of those layers live in the client's arena row only: the row starts
+        # every round from the global model (also after a rollback), the trainer adds the
+        # epoch's steps to it, and the module's own counter is never consulted.  Other
+        # integer buffers travel module <-> arena around the round.
+        self._counted = frozenset(counted)
+        self._count_idx = torch.tensor([pool.layout[n].offset for n in counted], dtype=torch.long,
+                                       device=self.device)
+        self._other_ints = any(
+            not b.dtype.is_floating_point and n not in self._counted and n in pool.layout
+            for n, b in self.modules[0].named_buffers()
+        ) if self.modules else False
         # Client streams (default priority) for the convolutional models.  Token
         # models stay on one stream: their large GEMMs may run as stream-K kernels,
         # whose workgroups wait for each other through memory - two of those
@@ -373,6 +387,9 @@ class TorchGroupTrainer(GroupTrainer):
         self._dp_step = round_idx * cfg.local_epochs * max(self.shards.max_steps(), 1) * max(G, 1)
         if self._direct:
             self._refresh_shadow()
+        if self._other_ints:
+            for k in range(G):
+                self.pool[k].push_int_buffers(self.modules[k], skip=self._counted)
         if self._streams is not None and G > 1:
             self._train_clients_concurrently(round_idx)
         else:
@@ -389,15 +406,15 @@ class TorchGroupTrainer(GroupTrainer):
                     steps = self.shards.steps_per_epoch(k)
                     for s in range(steps):
                         self._step(k, perm[s * cfg.batch_size : (s + 1) * cfg.batch_size])
-                    for m in self._bn_layers[k]:
-                        m.num_batches_tracked += steps
+                    self._count_steps(k, steps)
         for k in range(G):
             batches = self._acc[k, 2].clamp(min=1.0)
             self.metrics[k, M_SAMPLES] = float(self.shards.sizes[k])
             self.metrics[k, M_LOSS] = self._acc[k, 0] / batches
             self.metrics[k, M_ACC] = self._acc[k, 1] / batches
             self.metrics[k, M_VALID] = 1.0
-            self.pool[k].pull_int_buffers(self.modules[k])
+            if self._other_ints:
+                self.pool[k].pull_int_buffers(self.modules[k], skip=self._counted)
         if self._accountants is not None:
             # privacy spent is a function of the number of noisy steps since round 0
             eps = [
@@ -409,6 +426,13 @@ class TorchGroupTrainer(GroupTrainer):
             ]
             self.metrics[:, M_EPSILON] = torch.tensor(eps, dtype=torch.float32).to(self.device)
         return self.metrics
+
+    def _count_steps(self, k: int, steps: int) -> None:
+        """Add an epoch's optimisation steps to the BatchNorm step counters of client k."""
+        if self._count_idx.numel():
+            self.pool.data[k].index_add_(
+                0, self._count_idx,
+                torch.full((self._count_idx.numel(),), float(steps), device=self.device))
 
     def _train_clients_concurrently(self, round_idx: int) -> None:
         """Client k's steps go to stream k, enqueued step-major so that every
@@ -441,8 +465,7 @@ class TorchGroupTrainer(GroupTrainer):
                             self._step(k, perms[k][epoch][lo : lo + cfg.batch_size])
             for k in range(G):
                 with torch.cuda.stream(self._streams[k]):
-                    for m in self._bn_layers[k]:
-                        m.num_batches_tracked += steps[k]
+                    self._count_steps(k, steps[k])
         for st in set(self._streams):
             main.wait_stream(st)
         del perms  # released only after the main stream has joined the client streams

@@ -293,18 +293,19 @@ class ParameterArena:
                 _set_buffer(module, name, views[name])
         return module
 
-    def pull_int_buffers(self, module: nn.Module) -> None:
-        """module integer buffers -> arena (before aggregation)."""
+    def pull_int_buffers(self, module: nn.Module, skip: frozenset[str] = frozenset()) -> None:
+        """module integer buffers -> arena (before aggregation); ``skip``: names that
+        are maintained in the arena itself."""
         views = self.views()
         for name, b in module.named_buffers():
-            if name in views and not b.dtype.is_floating_point:
+            if name in views and name not in skip and not b.dtype.is_floating_point:
                 views[name].copy_(b.to(torch.float32))
 
-    def push_int_buffers(self, module: nn.Module) -> None:
+    def push_int_buffers(self, module: nn.Module, skip: frozenset[str] = frozenset()) -> None:
         """arena -> module integer buffers (after a new global model)."""
         views = self.views()
         for name, b in module.named_buffers():
-            if name in views and not b.dtype.is_floating_point:
+            if name in views and name not in skip and not b.dtype.is_floating_point:
                 b.copy_(views[name].round().to(b.dtype))
 
 

@@ -23,7 +23,8 @@ def _cos(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
-    return float((a.float() - b.float()).norm() / b.float().norm().clamp(min=1e-30))
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
 # Shapes of the four ResNet-18 stages; B * H * W is a multiple of 128 in each.
@@ -313,6 +314,7 @@ def test_graph_replays_equal_the_eager_steps_bit_for_bit():
     b.run(2)
     assert len(b.trainer._ggraphs) == 1
     assert torch.equal(a.global_arena.data, b.global_arena.data)
+    assert int(b.global_state_dict()["bn1.num_batches_tracked"]) == 8  # 4 rounds of 2 steps
 
 
 def test_unequal_shards_and_ragged_tails():
@@ -325,3 +327,33 @@ def test_unequal_shards_and_ragged_tails():
     assert torch.isfinite(eng.global_arena.data).all()
     keys = set(eng.trainer._ggraphs)
     assert (0, 3) in keys and len(keys) >= 2
+
+
+def test_faults_and_rollback_leave_the_trainer_consistent(tmp_path):
+    """A dropped client, a poisoned update and a failed round (rolled back to the last
+    checkpoint) on the grouped trainer: the run ends with the same model as a run in
+    which only the drop and the poison happen."""
+    from nanofed_amd.engine import FaultPlan
+
+    def run(fail: bool, base):
+        torch.cuda.set_device(0)
+        cfg = EngineConfig(model="resnet18", dataset="synthetic_cifar10", num_clients=3,
+                           samples_per_client=64, batch_size=32, local_epochs=1, eval_samples=64,
+                           learning_rate=0.05, seed=9, backend="native", checkpoint_rounds=True,
+                           max_update_norm=1000.0)
+        faults = FaultPlan(drop={0: {2}}, poison={1: {0}},
+                           fail={2: "HIP error: injected"} if fail else {})
+        eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)),
+                              base_dir=base, faults=faults)
+        reps = eng.run(4)
+        eng.flush()
+        return eng, reps
+
+    a, ra = run(False, tmp_path / "a")
+    b, rb = run(True, tmp_path / "b")
+    assert [r.status for r in ra] == ["COMPLETED"] * 4
+    assert [r.status for r in rb if r.status == "COMPLETED"] == ["COMPLETED"] * 4
+    assert b.recoveries == 1
+    assert ra[0].num_clients == 2 and ra[1].num_clients == 2
+    assert torch.equal(a.global_arena.data, b.global_arena.data)
+    assert int(b.global_state_dict()["bn1.num_batches_tracked"]) == 8  # 4 rounds of 2 steps
