@@ -112,3 +112,35 @@ def test_rccl_collectives_single_rank_rehearsal(tmp_path, algo):
     assert got["max"] == 1.5
     torch.testing.assert_close(got["flat"], single.global_arena.data.cpu(), rtol=0, atol=0)
     assert got["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-6)
+
+
+RESNET_CFG = dict(model="resnet18", dataset="synthetic_cifar10", num_clients=3,
+                  samples_per_client=[96, 64, 64], batch_size=32, local_epochs=1, eval_samples=64,
+                  learning_rate=0.05, backend="native", seed=7)
+
+
+def test_grouped_resnet_two_ranks_track_one_rank(tmp_path):
+    """The ResNet trainer that steps all clients of a rank per launch: clients 0-1 on one
+    rank and client 2 on the other against all three in one group.  The group size picks
+    the convolution tile (another summation order), so the models agree to bf16 noise,
+    not bit for bit."""
+    out = tmp_path / "dist.pt"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, cfg=RESNET_CFG, out=str(out)))
+    proc = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+        capture_output=True, text=True, timeout=280, env=dict(os.environ, MASTER_ADDR="127.0.0.1"),
+    )
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    dist = torch.load(out, weights_only=True)
+    torch.cuda.set_device(0)
+    single = FederatedEngine(EngineConfig(**RESNET_CFG),
+                             comm=Communicator(device=torch.device("cuda", 0)))
+    reps = single.run(1)
+    assert type(single.trainer).__name__ == "ResNetNativeTrainer"
+    assert dist["weights"] == pytest.approx([96 / 224, 64 / 224, 64 / 224])
+    ref = single.global_arena.data.cpu()
+    rel = float((dist["flat"] - ref).norm() / ref.norm())
+    assert rel < 0.02, rel
+    assert dist["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=0.05)
