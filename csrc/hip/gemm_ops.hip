@@ -75,6 +75,7 @@ struct GemmArgs {
     int splits;       // 1 = plain mode
     int tiles_m, tiles_n;
     long sA, sB, sC;  // batched launches: elements between consecutive problems (blockIdx.z)
+    long sBias;       // ... between their bias vectors (C2 moves with C)
 };
 
 // tanh-GELU, the arithmetic of gelu_fwd_kernel in nn_ops.hip (same bits)
@@ -167,6 +168,8 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     g.A += blockIdx.z * g.sA;
     g.B += blockIdx.z * g.sB;
     g.C += blockIdx.z * g.sC;
+    if (g.C2 != nullptr) g.C2 += blockIdx.z * g.sC;
+    if (g.bias != nullptr) g.bias += blockIdx.z * g.sBias;
 
     // K range of this workgroup (split-K: contiguous ranges of whole K steps); only
     // the very last step of the matrix can be partial
@@ -461,10 +464,13 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restric
                                                           bf16* __restrict__ out,
                                                           bf16* __restrict__ out2,
                                                           const bf16* __restrict__ bias, long ldc,
-                                                          int M, int N, int splits, long sC) {
+                                                          int M, int N, int splits, long sC,
+                                                          long sBias) {
     const long total = static_cast<long>(M) * N;
     slabs += static_cast<long>(blockIdx.y) * splits * total;  // blockIdx.y: problem of a batch
     out += blockIdx.y * sC;
+    if (out2 != nullptr) out2 += blockIdx.y * sC;
+    if (bias != nullptr) bias += blockIdx.y * sBias;
     const long stride = static_cast<long>(gridDim.x) * blockDim.x;
     if ((N & 3) == 0) {
         const long total4 = total >> 2;
@@ -549,10 +555,10 @@ int nf_gemm_geometries() { return 5; }
 // by a second launch, which also applies bias / C2.  bias / C2 may be null.
 // geo: workgroup tile, see nf_gemm_geometries.
 // batch > 1: that many problems of one shape in one launch; problem b reads A + b sA,
-// B + b sB and writes C + b sC (elements; multiples of 8).  No bias / C2 then.
+// B + b sB, bias + b sBias and writes C + b sC, C2 + b sC (elements; multiples of 8).
 int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void* C, void* C2,
                          const void* bias, float* slabs, int M, int N, int K, long lda, long ldb,
-                         long ldc, int splits, int batch, long sA, long sB, long sC,
+                         long ldc, int splits, int batch, long sA, long sB, long sC, long sBias,
                          hipStream_t stream) {
     if (M < 1 || N < 1 || K < 1 || splits < 1 || splits > 64 || batch < 1 || batch > 65535) return -1;
     if ((lda & 7) || (ldb & 7) || (ldc & 7)) return -2;
@@ -560,7 +566,7 @@ int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void
          reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(C2)) & 15)
         return -3;
     if (splits > 1 && slabs == nullptr) return -4;
-    if (batch > 1 && (C2 != nullptr || bias != nullptr || ((sA | sB | sC) & 7) != 0)) return -9;
+    if (batch > 1 && ((sA | sB | sC | sBias) & 7) != 0) return -9;
     // leading dimensions must cover the rows the kernel reads (16-byte pieces)
     const long need_a = layout == 2 ? ((M + 7) & ~7) : ((K + 7) & ~7);
     const long need_b = layout == 0 ? ((K + 7) & ~7) : ((N + 7) & ~7);
@@ -580,6 +586,7 @@ int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void
     g.splits = splits;
     g.tiles_m = g.tiles_n = 0;
     g.sA = batch > 1 ? sA : 0; g.sB = batch > 1 ? sB : 0; g.sC = batch > 1 ? sC : 0;
+    g.sBias = batch > 1 ? sBias : 0;
     int rc;
     switch (layout) {
     case 0: rc = launch_geo<false, false>(geo, g, batch, stream); break;
@@ -595,7 +602,7 @@ int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3(static_cast<unsigned>(blocks), batch), dim3(256),
                            0, stream, slabs, static_cast<bf16*>(C), static_cast<bf16*>(C2),
-                           static_cast<const bf16*>(bias), ldc, M, N, splits, g.sC);
+                           static_cast<const bf16*>(bias), ldc, M, N, splits, g.sC, g.sBias);
         return static_cast<int>(hipGetLastError());
     }
     return 0;
@@ -605,7 +612,7 @@ int nf_gemm_bf16(int layout, int geo, const void* A, const void* B, void* C, voi
                  const void* bias, float* slabs, int M, int N, int K, long lda, long ldb, long ldc,
                  int splits, hipStream_t stream) {
     return nf_gemm_bf16_batched(layout, geo, A, B, C, C2, bias, slabs, M, N, K, lda, ldb, ldc,
-                                splits, 1, 0, 0, 0, stream);
+                                splits, 1, 0, 0, 0, 0, stream);
 }
 
 }  // extern "C"

@@ -20,7 +20,16 @@ trainer runs the step by hand on flat buffers:
   bias and GELU in the forward epilogue); ``NANOFED_NATIVE_GEMM=0`` routes them to
   hipBLASLt through ``torch.mm`` / ``torch.addmm`` instead, for comparison.
 
-Activations are bf16, statistics and losses fp32.  The G clients of a GPU are
+Activations are bf16, statistics and losses fp32.
+
+Clients.  With equal shards the clients of a GPU step together (``grouped``): their
+batches are stacked, every GEMM is ONE batched launch in which workgroup z reads
+client z's weights (``nf_gemm_bf16_batched``: a 4096-row layer GEMM alone makes 1.1
+rounds of workgroups and needs split-K for its weight gradient; eight of them fill the
+chip evenly - 233 us instead of 361 us per layer and client), attention, the
+cross-entropy and SGD are one launch for all clients, and only the kernels that read
+per-client vectors (LayerNorm, embeddings, bias gradients) are issued per client on row
+slices.  Otherwise (unequal shards, ``NANOFED_GPT2_GROUP=0``, lanes) the clients are
 trained one after the other and share the activation and gradient buffers.
 """
 
@@ -35,7 +44,9 @@ from nanofed_amd.core.exceptions import DeviceError
 from nanofed_amd.models.gpt2 import GPT2Config
 from nanofed_amd.ops import attention as attn_ops
 from nanofed_amd.ops import gemm_ops
+from nanofed_amd.ops import group_ops as go
 from nanofed_amd.ops import nn_ops
+from nanofed_amd.ops.group_ops import Ref
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
 from nanofed_amd.utils.streams import side_stream
 
@@ -48,6 +59,8 @@ BF16 = torch.bfloat16
 
 # concurrent client steps of the profiled shape (see GPT2NativeTrainer.__init__)
 LANES = int(os.environ.get("NANOFED_GPT2_LANES", "1"))
+# clients stepped together (0 = one after the other); activations grow with the group
+GROUP = int(os.environ.get("NANOFED_GPT2_GROUP", "8"))
 
 
 def _views(layout: ArenaLayout, flat: torch.Tensor) -> dict[str, torch.Tensor]:
@@ -149,6 +162,13 @@ class GPT2NativeTrainer(GroupTrainer):
                 raise DeviceError("token id outside the vocabulary")
         self.metrics = torch.zeros(G, METRIC_COLUMNS, dtype=torch.float32, device=self.device)
         self._acc = torch.zeros(G, 3, dtype=torch.float32, device=self.device)
+        # grouped steps: equal shards of full batches, one lane, the native GEMM path
+        self.group = 0
+        if (GROUP > 1 and G > 1 and self.lanes == 1 and self.native_gemm and full_batches
+                and self.device.type == "cuda" and len(set(shards.sizes)) == 1):
+            self.group = min(GROUP, G)
+            self._ggrads = torch.zeros(self.group, n, dtype=BF16, device=self.device)
+            self._gslabs = torch.empty(1, dtype=torch.float32, device=self.device)
 
     # -- buffers ------------------------------------------------------------
     def _buffers(self, batch: int, seq: int, lane: int = 0) -> _Buffers:
@@ -280,11 +300,168 @@ class GPT2NativeTrainer(GroupTrainer):
         self._backward(w, tokens, b, self._gvs[0])
         return float(b.loss_rows.mean()), self._gvs[0]
 
+    # -- grouped step: clients g0 .. g0 + Gn - 1 together ---------------------------------
+    def _off(self, name: str) -> int:
+        return self.layout[name].offset
+
+    def _gemm(self, layout: int, a: torch.Tensor, b_ptr: int, c_ptr: int, M: int, N: int, K: int,
+              lda: int, ldb: int, ldc: int, Gn: int, sa: int, sb: int, sc: int,
+              bias: Ref | None = None, c2: torch.Tensor | None = None) -> None:
+        need = go.gemm_slab_floats(M, N, K, layout, Gn)
+        if need > self._gslabs.numel():
+            self._gslabs = torch.empty(need, dtype=torch.float32, device=self.device)
+        go.gemm_batched(layout, a.data_ptr(), b_ptr, c_ptr, M, N, K, lda, ldb, ldc, Gn, sa, sb, sc,
+                        self._gslabs, go._stream(a),
+                        bias=bias.ptr.value if bias is not None else None,
+                        sbias=bias.stride if bias is not None else 0,
+                        c2=c2.data_ptr() if c2 is not None else None)
+
+    def _glin_fwd(self, x: torch.Tensor, wname: str, bname: str | None, out: torch.Tensor,
+                  g0: int, Gn: int, R: int, gelu_out: torch.Tensor | None = None,
+                  n_out: int | None = None) -> None:
+        """out[g] = x[g] w[g]^T (+ bias[g]) for every client of the group; x ``[Gn * R, K]``,
+        out ``[Gn * R, >= N]`` (rows may be longer than N: the padded logits)."""
+        N, K = self.layout[wname].shape
+        w = Ref(self.shadow[g0:], self._off(wname))
+        bias = Ref(self.shadow[g0:], self._off(bname)) if bname is not None else None
+        self._gemm(gemm_ops.NT, x, w.ptr.value, out.data_ptr(), R, n_out or N, K, x.stride(0), K,
+                   out.stride(0), Gn, R * x.stride(0), w.stride, R * out.stride(0), bias, gelu_out)
+
+    def _glin_dgrad(self, dy: torch.Tensor, wname: str, out: torch.Tensor, g0: int, Gn: int,
+                    R: int, n_in: int | None = None) -> None:
+        """out[g] = dy[g] w[g]; dy ``[Gn * R, >= N]``, out ``[Gn * R, K]``."""
+        N, K = self.layout[wname].shape
+        w = Ref(self.shadow[g0:], self._off(wname))
+        self._gemm(gemm_ops.NN, dy, w.ptr.value, out.data_ptr(), R, K, n_in or N, dy.stride(0), K,
+                   out.stride(0), Gn, R * dy.stride(0), w.stride, R * out.stride(0))
+
+    def _glin_wgrad(self, dy: torch.Tensor, x: torch.Tensor, wname: str, Gn: int, R: int,
+                    n_out: int | None = None) -> None:
+        """grad(w)[g] = dy[g]^T x[g], written into the group's gradient rows."""
+        N, K = self.layout[wname].shape
+        dw = Ref(self._ggrads, self._off(wname))
+        self._gemm(gemm_ops.TN, dy, x.data_ptr(), dw.ptr.value, n_out or N, K, R, dy.stride(0),
+                   x.stride(0), K, Gn, R * dy.stride(0), R * x.stride(0), dw.stride)
+
+    def _gstep(self, g0: int, Gn: int, tokens: torch.Tensor) -> None:
+        """One optimisation step of Gn clients; ``tokens`` ``[Gn * batch, seq + 1]``,
+        client-major."""
+        cfg, m, L = self.cfg, self.m, self.m.n_layer
+        nb = tokens.shape[0] // Gn                       # sequences per client
+        b = self._buffers(tokens.shape[0], tokens.shape[1] - 1, lane=100 + Gn)
+        R, V = nb * b.seq, m.vocab_size                   # rows per client
+        ws = [_views(self.layout, self.shadow[g0 + j]) for j in range(Gn)]
+        gs = [_views(self.layout, self._ggrads[j]) for j in range(Gn)]
+        rows = [slice(j * R, (j + 1) * R) for j in range(Gn)]
+        inp = tokens[:, :-1].contiguous()
+        tgt = tokens[:, 1:].contiguous().view(-1)
+        flat_inp = inp.view(-1)
+
+        def ln(j, x, name, out, st, delta=None, x_out=None):
+            nn_ops.ln_fwd(x[rows[j]], ws[j][name + ".weight"], ws[j][name + ".bias"], out[rows[j]],
+                          st[0][rows[j]], st[1][rows[j]],
+                          delta=delta[rows[j]] if delta is not None else None,
+                          x_out=x_out[rows[j]] if x_out is not None else None)
+
+        # forward
+        for j in range(Gn):
+            nn_ops.embed_fwd(flat_inp[rows[j]], ws[j]["wte.weight"], ws[j]["wpe.weight"], b.seq,
+                             out=b.x[0][rows[j]])
+        delta = None
+        for l in range(L):
+            p = f"h.{l}."
+            st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
+            for j in range(Gn):
+                if l == 0:
+                    ln(j, b.x[0], p + "ln_1", b.ln1[0], st1)
+                else:
+                    ln(j, b.x_mid[l - 1], p + "ln_1", b.ln1[l], st1, delta=delta, x_out=b.x[l])
+            self._glin_fwd(b.ln1[l], p + "attn.c_attn.weight", p + "attn.c_attn.bias", b.qkv[l],
+                           g0, Gn, R)
+            attn_ops.causal_attention_fwd(b.qkv[l], b.att[l], b.lse[l], b.batch, b.seq, m.n_head)
+            self._glin_fwd(b.att[l], p + "attn.c_proj.weight", p + "attn.c_proj.bias", b.tmp_c,
+                           g0, Gn, R)
+            for j in range(Gn):
+                ln(j, b.x[l], p + "ln_2", b.ln2[l], st2, delta=b.tmp_c, x_out=b.x_mid[l])
+            self._glin_fwd(b.ln2[l], p + "c_fc.weight", p + "c_fc.bias", b.fc[l], g0, Gn, R,
+                           gelu_out=b.act[l])
+            self._glin_fwd(b.act[l], p + "c_proj.weight", p + "c_proj.bias", b.tmp_c, g0, Gn, R)
+            delta = b.tmp_c
+        stf = b.stats[2 * L]
+        for j in range(Gn):
+            ln(j, b.x_mid[L - 1], "ln_f", b.lnf, stf, delta=delta, x_out=b.x[L])
+        self._glin_fwd(b.lnf, "wte.weight", None, b.logits, g0, Gn, R, n_out=V)
+        nn_ops.cross_entropy_fwd_bwd(b.logits, tgt, V, 1.0 / R, b.loss_rows, b.correct_rows)
+
+        # backward
+        def ln_b(j, dy, x, name, st, dres=None, dxsum=None):
+            nn_ops.ln_bwd(dy[rows[j]], x[rows[j]], ws[j][name + ".weight"], st[0][rows[j]],
+                          st[1][rows[j]], b.dres[rows[j]], gs[j][name + ".weight"],
+                          gs[j][name + ".bias"],
+                          dres=dres[rows[j]] if dres is not None else None, dxsum=dxsum)
+
+        self._glin_wgrad(b.logits, b.lnf, "wte.weight", Gn, R, n_out=V)
+        self._glin_dgrad(b.logits, "wte.weight", b.dln, g0, Gn, R, n_in=V)
+        for j in range(Gn):
+            ln_b(j, b.dln, b.x[L], "ln_f", stf, dxsum=gs[j][f"h.{L - 1}.c_proj.bias"])
+        for l in reversed(range(L)):
+            p = f"h.{l}."
+            st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
+            self._glin_wgrad(b.dres, b.act[l], p + "c_proj.weight", Gn, R)
+            self._glin_dgrad(b.dres, p + "c_proj.weight", b.dact, g0, Gn, R)
+            for j in range(Gn):
+                nn_ops.gelu_bwd_colsum(b.fc[l][rows[j]], b.dact[rows[j]], b.dact[rows[j]],
+                                       gs[j][p + "c_fc.bias"])
+            self._glin_wgrad(b.dact, b.ln2[l], p + "c_fc.weight", Gn, R)
+            self._glin_dgrad(b.dact, p + "c_fc.weight", b.dln, g0, Gn, R)
+            for j in range(Gn):
+                ln_b(j, b.dln, b.x_mid[l], p + "ln_2", st2, dres=b.dres,
+                     dxsum=gs[j][p + "attn.c_proj.bias"])
+            self._glin_wgrad(b.dres, b.att[l], p + "attn.c_proj.weight", Gn, R)
+            self._glin_dgrad(b.dres, p + "attn.c_proj.weight", b.datt, g0, Gn, R)
+            attn_ops.causal_attention_bwd(b.qkv[l], b.att[l], b.lse[l], b.datt, b.dqkv,
+                                          b.attn_scratch, b.batch, b.seq, m.n_head)
+            for j in range(Gn):
+                nn_ops.colsum(b.dqkv[rows[j]], gs[j][p + "attn.c_attn.bias"])
+            self._glin_wgrad(b.dqkv, b.ln1[l], p + "attn.c_attn.weight", Gn, R)
+            self._glin_dgrad(b.dqkv, p + "attn.c_attn.weight", b.dln, g0, Gn, R)
+            for j in range(Gn):
+                ln_b(j, b.dln, b.x[l], p + "ln_1", st1, dres=b.dres,
+                     dxsum=gs[j][f"h.{l - 1}.c_proj.bias"] if l > 0 else None)
+        for j in range(Gn):
+            nn_ops.embed_bwd(inp[j * nb : (j + 1) * nb], b.dres[rows[j]], gs[j]["wte.weight"],
+                             gs[j]["wpe.weight"], nb, b.seq)
+        n = self.layout.numel
+        nn_ops.sgd_step_bf16g(self.pool.data[g0 : g0 + Gn].view(-1), self._ggrads[:Gn].view(-1),
+                              self.shadow[g0 : g0 + Gn].view(-1), cfg.learning_rate,
+                              cfg.weight_decay)
+        assert self.pool.data.stride(0) == n
+        self._acc[g0 : g0 + Gn, 0] += b.loss_rows.view(Gn, R).mean(1)
+        self._acc[g0 : g0 + Gn, 1] += b.correct_rows.view(Gn, R).mean(1)
+        self._acc[g0 : g0 + Gn, 2] += 1.0
+
+    def _train_round_grouped(self, round_idx: int) -> None:
+        cfg = self.cfg
+        G, B = len(self.pool), cfg.batch_size
+        steps = self.shards.steps_per_epoch(0)
+        for epoch in range(cfg.local_epochs):
+            self._acc.zero_()
+            perms = torch.stack([self.shards.epoch_permutation(k, round_idx, epoch)
+                                 for k in range(G)]).view(G, steps, B)
+            for s in range(steps):
+                for g0 in range(0, G, self.group):
+                    Gn = min(self.group, G - g0)
+                    rows = perms[g0 : g0 + Gn, s].reshape(-1)
+                    self._gstep(g0, Gn, self.shards.inputs[rows])
+
     def train_round(self, round_idx: int) -> torch.Tensor:
         cfg = self.cfg
         G = len(self.pool)
         self.metrics.zero_()
         self.shadow.copy_(self.pool.data)  # the round starts from the broadcast model
+        if self.group:
+            self._train_round_grouped(round_idx)
+            return self._round_metrics()
         steps = [self.shards.steps_per_epoch(k) for k in range(G)]
         perms = [
             [self.shards.epoch_permutation(k, round_idx, e) for e in range(cfg.local_epochs)]
@@ -319,6 +496,10 @@ class GPT2NativeTrainer(GroupTrainer):
             for st in self._streams:
                 main.wait_stream(st)
         del perms
+        return self._round_metrics()
+
+    def _round_metrics(self) -> torch.Tensor:
+        G = len(self.pool)
         for k in range(G):
             batches = self._acc[k, 2].clamp(min=1.0)
             self.metrics[k, M_SAMPLES] = float(self.shards.sizes[k])

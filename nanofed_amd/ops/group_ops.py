@@ -35,7 +35,7 @@ _SIGS = {
     "nf_bn_fwd_g": ([P, P, P, P, P, P, P, P, P, I, L, I, I, FL, FL, I, L, P], I),
     "nf_bn_bwd_g": ([P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, L, I, L, P], I),
     "nf_bn_workspace_floats": ([I], I),
-    "nf_gemm_bf16_batched": ([I, I, P, P, P, P, P, P, I, I, I, L, L, L, I, I, L, L, L, P], I),
+    "nf_gemm_bf16_batched": ([I, I, P, P, P, P, P, P, I, I, I, L, L, L, I, I, L, L, L, L, P], I),
     "nf_im2col": ([P, P, I, I, I, I, I, I, I, I, I, I, I, P], I),
     "nf_col2im": ([P, P, I, I, I, I, I, I, I, I, I, I, I, P], I),
     "nf_stem_patches": ([P, P, P, I, I, I, P, P, P], I),
@@ -190,17 +190,20 @@ def gemm_slab_floats(M: int, N: int, K: int, layout: int, batch: int) -> int:
 
 def gemm_batched(layout: int, a: c_void_p, b: c_void_p, c: c_void_p, M: int, N: int, K: int,
                  lda: int, ldb: int, ldc: int, batch: int, sa: int, sb: int, sc: int,
-                 slabs: torch.Tensor | None, stream: c_void_p) -> None:
+                 slabs: torch.Tensor | None, stream: c_void_p, bias: int | None = None,
+                 sbias: int = 0, c2: int | None = None) -> None:
     """``batch`` GEMMs of one shape (layouts as in ``gemm_ops``); problem i uses
-    ``a + i sa``, ``b + i sb``, ``c + i sc`` (elements)."""
+    ``a + i sa``, ``b + i sb``, ``c + i sc`` (elements).  ``bias`` (address of problem
+    0's bf16 vector, ``sbias`` elements apart) is added to the result; ``c2`` receives
+    ``gelu(c)`` with the strides of ``c``."""
     geo = gemm_ops.choose_geometry(M, N, K, layout, batch)
     splits = gemm_ops.choose_splits(M, N, K, geo, batch)
     if splits > 1 and (slabs is None or slabs.numel() < batch * splits * M * N):
         raise DeviceError("gemm_batched: the split-K buffer is too small")
     library.check(
-        _fn("nf_gemm_bf16_batched")(layout, geo, a, b, c, None, None,
+        _fn("nf_gemm_bf16_batched")(layout, geo, a, b, c, c2, bias,
                                     _p(slabs) if splits > 1 else None, M, N, K, lda, ldb, ldc,
-                                    splits, batch, sa, sb, sc, stream),
+                                    splits, batch, sa, sb, sc, sbias, stream),
         "nf_gemm_bf16_batched",
     )
 
