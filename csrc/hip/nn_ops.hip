@@ -126,10 +126,16 @@ template <bool kHasDelta, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf16* delta,
                                                      bf16* x_out, const bf16* gamma,
                                                      const bf16* beta, bf16* y, float* mean,
-                                                     float* rstd, int R, int C, float eps) {
+                                                     float* rstd, int R, int C, float eps,
+                                                     int Rg, long ps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= R) return;
+    if (ps != 0) {  // grouped: rows [g Rg, (g + 1) Rg) use the vectors of group g
+        const long shift = (row / Rg) * ps;
+        gamma += shift;
+        beta += shift;
+    }
     const long base = static_cast<long>(row) * C;
     float v[NCH][4];
     float s = 0.f;
@@ -186,10 +192,11 @@ template <bool kHasRes, int NCH>
 __global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const bf16* dy, const bf16* x,
                                                         const bf16* gamma, const float* mean,
                                                         const float* rstd, const bf16* dres,
-                                                        bf16* dx, int R, int C) {
+                                                        bf16* dx, int R, int C, int Rg, long ps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= R) return;
+    if (ps != 0) gamma += (row / Rg) * ps;
     const long base = static_cast<long>(row) * C;
     const float mu = mean[row], rs = rstd[row];
     float xh[NCH][4], dyw[NCH][4];
@@ -239,6 +246,15 @@ __global__ void __launch_bounds__(256) ln_bwd_cols_kernel(const bf16* dy, const 
                                                           const float* rstd, float* partial,
                                                           int R, int C, int rows_per_chunk) {
     __shared__ float red[4][3][512];
+    {   // blockIdx.z: group of R rows
+        const long rofs = static_cast<long>(blockIdx.z) * R;
+        dy += rofs * C;
+        x += rofs * C;
+        dx += rofs * C;
+        mean += rofs;
+        rstd += rofs;
+        partial += static_cast<long>(blockIdx.z) * gridDim.y * 3 * C;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 512 + lane * 8;
     const int r0 = blockIdx.y * rows_per_chunk;
@@ -282,8 +298,12 @@ __global__ void __launch_bounds__(256) ln_bwd_cols_kernel(const bf16* dy, const 
 // 64 columns per workgroup; wave w sums a quarter of the partial rows.
 __global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* partial, bf16* dgamma,
                                                             bf16* dbeta, bf16* dxsum, int nblocks,
-                                                            int C) {
+                                                            int C, long gs) {
     __shared__ float red[4][64];
+    partial += static_cast<long>(blockIdx.y) * nblocks * 3 * C;  // blockIdx.y: group
+    dgamma += blockIdx.y * gs;
+    dbeta += blockIdx.y * gs;
+    if (dxsum != nullptr) dxsum += blockIdx.y * gs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f;
@@ -343,6 +363,8 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const bf16* x, const bf16
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const bf16* m, float* partial, int R,
                                                              int N, long ld, int rows_per_chunk) {
     __shared__ float red[4][128];
+    m += static_cast<long>(blockIdx.z) * R * ld;  // blockIdx.z: group of R rows
+    partial += static_cast<long>(blockIdx.z) * gridDim.y * N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 128 + lane * 2;
     const int r0 = blockIdx.y * rows_per_chunk;
@@ -376,6 +398,15 @@ __global__ void __launch_bounds__(256) colsum8_partial_kernel(const bf16* m, con
                                                               bf16* dx, float* partial, int R,
                                                               int N, long ld, int rows_per_chunk) {
     __shared__ float red[4][512];
+    {   // blockIdx.z: group of R rows
+        const long gofs = static_cast<long>(blockIdx.z) * R * ld;
+        m += gofs;
+        if (kGelu) {
+            x += gofs;
+            dx += gofs;
+        }
+        partial += static_cast<long>(blockIdx.z) * gridDim.y * N;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 512 + lane * 8;
     const int r0 = blockIdx.y * rows_per_chunk;
@@ -414,8 +445,10 @@ __global__ void __launch_bounds__(256) colsum8_partial_kernel(const bf16* m, con
 
 // 64 columns per workgroup; wave w sums a quarter of the chunks.
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* partial, bf16* out,
-                                                           int chunks, int N) {
+                                                           int chunks, int N, long gs) {
     __shared__ float red[4][64];
+    partial += static_cast<long>(blockIdx.y) * chunks * N;  // blockIdx.y: group
+    out += blockIdx.y * gs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
     float s = 0.f;
@@ -570,14 +603,18 @@ int nf_embed_bwd(const long* sorted, const long* order, const void* dx, void* dw
 }
 
 // delta == nullptr: y = LN(x_in).  Otherwise x_out = x_in + delta, y = LN(x_out)
-// (x_out may alias x_in).
-int nf_ln_fwd(const void* x_in, const void* delta, void* x_out, const void* gamma,
-              const void* beta, void* y, float* mean, float* rstd, int R, int C, float eps,
-              hipStream_t s) {
-    if (R <= 0 || C <= 0 || C % 4 != 0 || C > kLnMaxChunks * 256) return -1;
+// (x_out may alias x_in).  G > 1: G groups of R rows stacked in the matrices, gamma / beta
+// of group g start ps elements after those of group g - 1.
+int nf_ln_fwd_g(const void* x_in, const void* delta, void* x_out, const void* gamma,
+                const void* beta, void* y, float* mean, float* rstd, int G, int R, int C,
+                float eps, long ps, hipStream_t s) {
+    if (G < 1 || R <= 0 || C <= 0 || C % 4 != 0 || C > kLnMaxChunks * 256) return -1;
     if (!aligned(x_in, 8) || !aligned(y, 8) || !aligned(gamma, 8) || !aligned(beta, 8)) return -2;
     if (delta != nullptr && (x_out == nullptr || !aligned(delta, 8) || !aligned(x_out, 8))) return -2;
-    const dim3 grid((R + 3) / 4), block(256);
+    if (G > 1 && (ps % 4 != 0 || static_cast<long>(G) * R >= (1L << 31))) return -3;
+    const int RT = G * R;
+    const long pstride = G > 1 ? ps : 0;
+    const dim3 grid((RT + 3) / 4), block(256);
     const bf16* xi = static_cast<const bf16*>(x_in);
     const bf16* dl = static_cast<const bf16*>(delta);
     bf16* xo = static_cast<bf16*>(x_out);
@@ -588,10 +625,10 @@ int nf_ln_fwd(const void* x_in, const void* delta, void* x_out, const void* gamm
     case N:                                                                                   \
         if (delta != nullptr)                                                                 \
             hipLaunchKernelGGL((ln_fwd_kernel<true, N>), grid, block, 0, s, xi, dl, xo, ga, be, yo, \
-                               mean, rstd, R, C, eps);                                        \
+                               mean, rstd, RT, C, eps, R, pstride);                           \
         else                                                                                  \
             hipLaunchKernelGGL((ln_fwd_kernel<false, N>), grid, block, 0, s, xi, nullptr, nullptr, \
-                               ga, be, yo, mean, rstd, R, C, eps);                            \
+                               ga, be, yo, mean, rstd, RT, C, eps, R, pstride);               \
         break;
     switch ((C + 255) / 256) {
         NF_LN_FWD(1) NF_LN_FWD(2) NF_LN_FWD(3) NF_LN_FWD(4)
@@ -602,34 +639,46 @@ int nf_ln_fwd(const void* x_in, const void* delta, void* x_out, const void* gamm
     return NF_NN_OK();
 }
 
+int nf_ln_fwd(const void* x_in, const void* delta, void* x_out, const void* gamma,
+              const void* beta, void* y, float* mean, float* rstd, int R, int C, float eps,
+              hipStream_t s) {
+    return nf_ln_fwd_g(x_in, delta, x_out, gamma, beta, y, mean, rstd, 1, R, C, eps, 0, s);
+}
+
 // row chunks of the column-sum pass
 int nf_ln_bwd_blocks(int R) {
     (void)R;
     return 64;
 }
 
-// partial: nf_ln_bwd_blocks(R) * 3 * C floats of workspace.  dres may be null;
+// partial: G * nf_ln_bwd_blocks(R) * 3 * C floats of workspace.  dres may be null;
 // dx may alias dres (not dy).  dxsum (may be null) receives the column sums of dx.
-int nf_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
-              const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
-              void* dxsum, float* partial, int R, int C, hipStream_t s) {
-    if (R <= 0 || C <= 0 || C % 8 != 0 || C > kLnMaxChunks * 256) return -1;
+// G > 1: G groups of R rows; gamma of group g starts ps elements after that of group
+// g - 1, dgamma / dbeta / dxsum of group g start gs elements after those of group g - 1.
+int nf_ln_bwd_g(const void* dy, const void* x, const void* gamma, const float* mean,
+                const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
+                void* dxsum, float* partial, int G, int R, int C, long ps, long gs,
+                hipStream_t s) {
+    if (G < 1 || G > 65535 || R <= 0 || C <= 0 || C % 8 != 0 || C > kLnMaxChunks * 256) return -1;
     if (!aligned(dy, 16) || !aligned(x, 16) || !aligned(dx, 16) || !aligned(gamma, 8)) return -2;
     if (dres != nullptr && !aligned(dres, 8)) return -2;
+    if (G > 1 && (ps % 4 != 0 || static_cast<long>(G) * R >= (1L << 31))) return -3;
     const bf16* dyp = static_cast<const bf16*>(dy);
     const bf16* xp = static_cast<const bf16*>(x);
     const bf16* ga = static_cast<const bf16*>(gamma);
     const bf16* dr = static_cast<const bf16*>(dres);
     bf16* dxp = static_cast<bf16*>(dx);
-    const dim3 grid((R + 3) / 4), block(256);
+    const int RT = G * R;
+    const long pstride = G > 1 ? ps : 0;
+    const dim3 grid((RT + 3) / 4), block(256);
 #define NF_LN_BWD(N)                                                                          \
     case N:                                                                                   \
         if (dres != nullptr)                                                                  \
             hipLaunchKernelGGL((ln_bwd_dx_kernel<true, N>), grid, block, 0, s, dyp, xp, ga, mean, \
-                               rstd, dr, dxp, R, C);                                          \
+                               rstd, dr, dxp, RT, C, R, pstride);                             \
         else                                                                                  \
             hipLaunchKernelGGL((ln_bwd_dx_kernel<false, N>), grid, block, 0, s, dyp, xp, ga, mean, \
-                               rstd, nullptr, dxp, R, C);                                     \
+                               rstd, nullptr, dxp, RT, C, R, pstride);                        \
         break;
     switch ((C + 255) / 256) {
         NF_LN_BWD(1) NF_LN_BWD(2) NF_LN_BWD(3) NF_LN_BWD(4)
@@ -639,12 +688,19 @@ int nf_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mea
 #undef NF_LN_BWD
     const int nb = nf_ln_bwd_blocks(R);
     const int rows = (R + nb - 1) / nb;
-    hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3((C + 511) / 512, nb), dim3(256), 0, s, dyp, xp,
+    hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3((C + 511) / 512, nb, G), dim3(256), 0, s, dyp, xp,
                        static_cast<const bf16*>(dx), mean, rstd, partial, R, C, rows);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * C + 63) / 64), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * C + 63) / 64, G), dim3(256), 0, s, partial,
                        static_cast<bf16*>(dgamma), static_cast<bf16*>(dbeta),
-                       static_cast<bf16*>(dxsum), nb, C);
+                       static_cast<bf16*>(dxsum), nb, C, G > 1 ? gs : 0);
     return NF_NN_OK();
+}
+
+int nf_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
+              const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
+              void* dxsum, float* partial, int R, int C, hipStream_t s) {
+    return nf_ln_bwd_g(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dxsum, partial, 1, R, C,
+                       0, 0, s);
 }
 
 int nf_gelu_fwd(const void* x, void* y, long n, hipStream_t s) {
@@ -664,37 +720,51 @@ int nf_gelu_bwd(const void* x, const void* dy, void* dx, long n, hipStream_t s) 
 
 int nf_colsum_chunks() { return 64; }
 
-// out[c] = sum_r m[r][c]; partial: nf_colsum_chunks() * N floats of workspace.
-int nf_colsum(const void* m, void* out, float* partial, int R, int N, long ld, hipStream_t s) {
-    if (R <= 0 || N <= 0 || N % 2 != 0 || ld % 2 != 0 || ld < N || !aligned(m, 4)) return -1;
-    const int chunks = nf_colsum_chunks();
-    const int rows = (R + chunks - 1) / chunks;
-    if (N % 8 == 0 && ld % 8 == 0 && aligned(m, 16))
-        hipLaunchKernelGGL(colsum8_partial_kernel<false>, dim3((N + 511) / 512, chunks), dim3(256),
-                           0, s, static_cast<const bf16*>(m), nullptr, nullptr, partial, R, N, ld,
-                           rows);
-    else
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 127) / 128, chunks), dim3(256), 0, s,
-                           static_cast<const bf16*>(m), partial, R, N, ld, rows);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, partial,
-                       static_cast<bf16*>(out), chunks, N);
-    return NF_NN_OK();
-}
-
-// dx = dy * gelu'(x) for contiguous [R][N] matrices (dx may alias dy) and
-// dbias[c] = sum_r dx[r][c], in one pass.
-int nf_gelu_bwd_colsum(const void* x, const void* dy, void* dx, void* dbias, float* partial, int R,
-                       int N, hipStream_t s) {
-    if (R <= 0 || N <= 0 || N % 8 != 0 || !aligned(x, 16) || !aligned(dy, 16) || !aligned(dx, 16))
+// out[g][c] = sum over the R rows of group g of m[r][c]; partial: G * nf_colsum_chunks() * N
+// floats of workspace; out of group g starts gs elements after that of group g - 1.
+int nf_colsum_g(const void* m, void* out, float* partial, int G, int R, int N, long ld, long gs,
+                hipStream_t s) {
+    if (G < 1 || G > 65535 || R <= 0 || N <= 0 || N % 2 != 0 || ld % 2 != 0 || ld < N ||
+        !aligned(m, 4))
         return -1;
     const int chunks = nf_colsum_chunks();
     const int rows = (R + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum8_partial_kernel<true>, dim3((N + 511) / 512, chunks), dim3(256), 0, s,
-                       static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
-                       static_cast<bf16*>(dx), partial, R, N, static_cast<long>(N), rows);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, partial,
-                       static_cast<bf16*>(dbias), chunks, N);
+    if (N % 8 == 0 && ld % 8 == 0 && aligned(m, 16))
+        hipLaunchKernelGGL(colsum8_partial_kernel<false>, dim3((N + 511) / 512, chunks, G),
+                           dim3(256), 0, s, static_cast<const bf16*>(m), nullptr, nullptr, partial,
+                           R, N, ld, rows);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 127) / 128, chunks, G), dim3(256), 0, s,
+                           static_cast<const bf16*>(m), partial, R, N, ld, rows);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64, G), dim3(256), 0, s, partial,
+                       static_cast<bf16*>(out), chunks, N, G > 1 ? gs : 0);
     return NF_NN_OK();
+}
+
+int nf_colsum(const void* m, void* out, float* partial, int R, int N, long ld, hipStream_t s) {
+    return nf_colsum_g(m, out, partial, 1, R, N, ld, 0, s);
+}
+
+// dx = dy * gelu'(x) for contiguous [G * R][N] matrices (dx may alias dy) and
+// dbias[g][c] = sum over the rows of group g of dx[r][c], in one pass.
+int nf_gelu_bwd_colsum_g(const void* x, const void* dy, void* dx, void* dbias, float* partial,
+                         int G, int R, int N, long gs, hipStream_t s) {
+    if (G < 1 || G > 65535 || R <= 0 || N <= 0 || N % 8 != 0 || !aligned(x, 16) ||
+        !aligned(dy, 16) || !aligned(dx, 16))
+        return -1;
+    const int chunks = nf_colsum_chunks();
+    const int rows = (R + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum8_partial_kernel<true>, dim3((N + 511) / 512, chunks, G), dim3(256), 0,
+                       s, static_cast<const bf16*>(dy), static_cast<const bf16*>(x),
+                       static_cast<bf16*>(dx), partial, R, N, static_cast<long>(N), rows);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64, G), dim3(256), 0, s, partial,
+                       static_cast<bf16*>(dbias), chunks, N, G > 1 ? gs : 0);
+    return NF_NN_OK();
+}
+
+int nf_gelu_bwd_colsum(const void* x, const void* dy, void* dx, void* dbias, float* partial, int R,
+                       int N, hipStream_t s) {
+    return nf_gelu_bwd_colsum_g(x, dy, dx, dbias, partial, 1, R, N, 0, s);
 }
 
 // logits: [R][ld] bf16 with V <= ld valid columns, ld a multiple of 8, base

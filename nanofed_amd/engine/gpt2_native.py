@@ -27,10 +27,11 @@ batches are stacked, every GEMM is ONE batched launch in which workgroup z reads
 client z's weights (``nf_gemm_bf16_batched``: a 4096-row layer GEMM alone makes 1.1
 rounds of workgroups and needs split-K for its weight gradient; eight of them fill the
 chip evenly - 233 us instead of 361 us per layer and client), attention, the
-cross-entropy and SGD are one launch for all clients, and only the kernels that read
-per-client vectors (LayerNorm, embeddings, bias gradients) are issued per client on row
-slices.  Otherwise (unequal shards, ``NANOFED_GPT2_GROUP=0``, lanes) the clients are
-trained one after the other and share the activation and gradient buffers.
+cross-entropy and SGD are one launch for all clients, LayerNorm and the bias-gradient
+column sums take the client from the row index, and only the embedding kernels (one table
+per client) are issued per client on row slices.  Otherwise (unequal shards,
+``NANOFED_GPT2_GROUP=0``, lanes) the clients are trained one after the other and share
+the activation and gradient buffers.
 """
 
 from __future__ import annotations
@@ -357,11 +358,15 @@ class GPT2NativeTrainer(GroupTrainer):
         tgt = tokens[:, 1:].contiguous().view(-1)
         flat_inp = inp.view(-1)
 
-        def ln(j, x, name, out, st, delta=None, x_out=None):
-            nn_ops.ln_fwd(x[rows[j]], ws[j][name + ".weight"], ws[j][name + ".bias"], out[rows[j]],
-                          st[0][rows[j]], st[1][rows[j]],
-                          delta=delta[rows[j]] if delta is not None else None,
-                          x_out=x_out[rows[j]] if x_out is not None else None)
+        def wref(name):      # bf16 parameter copy of the group's first client
+            return Ref(self.shadow[g0:], self._off(name))
+
+        def gref(name):      # gradient slot
+            return Ref(self._ggrads, self._off(name))
+
+        def ln(x, name, out, st, delta=None, x_out=None):
+            nn_ops.ln_fwd_g(x, wref(name + ".weight"), wref(name + ".bias"), out, st[0], st[1], Gn,
+                            delta=delta, x_out=x_out)
 
         # forward
         for j in range(Gn):
@@ -371,63 +376,52 @@ class GPT2NativeTrainer(GroupTrainer):
         for l in range(L):
             p = f"h.{l}."
             st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
-            for j in range(Gn):
-                if l == 0:
-                    ln(j, b.x[0], p + "ln_1", b.ln1[0], st1)
-                else:
-                    ln(j, b.x_mid[l - 1], p + "ln_1", b.ln1[l], st1, delta=delta, x_out=b.x[l])
+            if l == 0:
+                ln(b.x[0], p + "ln_1", b.ln1[0], st1)
+            else:
+                ln(b.x_mid[l - 1], p + "ln_1", b.ln1[l], st1, delta=delta, x_out=b.x[l])
             self._glin_fwd(b.ln1[l], p + "attn.c_attn.weight", p + "attn.c_attn.bias", b.qkv[l],
                            g0, Gn, R)
             attn_ops.causal_attention_fwd(b.qkv[l], b.att[l], b.lse[l], b.batch, b.seq, m.n_head)
             self._glin_fwd(b.att[l], p + "attn.c_proj.weight", p + "attn.c_proj.bias", b.tmp_c,
                            g0, Gn, R)
-            for j in range(Gn):
-                ln(j, b.x[l], p + "ln_2", b.ln2[l], st2, delta=b.tmp_c, x_out=b.x_mid[l])
+            ln(b.x[l], p + "ln_2", b.ln2[l], st2, delta=b.tmp_c, x_out=b.x_mid[l])
             self._glin_fwd(b.ln2[l], p + "c_fc.weight", p + "c_fc.bias", b.fc[l], g0, Gn, R,
                            gelu_out=b.act[l])
             self._glin_fwd(b.act[l], p + "c_proj.weight", p + "c_proj.bias", b.tmp_c, g0, Gn, R)
             delta = b.tmp_c
         stf = b.stats[2 * L]
-        for j in range(Gn):
-            ln(j, b.x_mid[L - 1], "ln_f", b.lnf, stf, delta=delta, x_out=b.x[L])
+        ln(b.x_mid[L - 1], "ln_f", b.lnf, stf, delta=delta, x_out=b.x[L])
         self._glin_fwd(b.lnf, "wte.weight", None, b.logits, g0, Gn, R, n_out=V)
         nn_ops.cross_entropy_fwd_bwd(b.logits, tgt, V, 1.0 / R, b.loss_rows, b.correct_rows)
 
         # backward
-        def ln_b(j, dy, x, name, st, dres=None, dxsum=None):
-            nn_ops.ln_bwd(dy[rows[j]], x[rows[j]], ws[j][name + ".weight"], st[0][rows[j]],
-                          st[1][rows[j]], b.dres[rows[j]], gs[j][name + ".weight"],
-                          gs[j][name + ".bias"],
-                          dres=dres[rows[j]] if dres is not None else None, dxsum=dxsum)
+        def ln_b(dy, x, name, st, dres=None, dxsum=None):
+            nn_ops.ln_bwd_g(dy, x, wref(name + ".weight"), st[0], st[1], b.dres,
+                            gref(name + ".weight"), gref(name + ".bias"), Gn, dres=dres,
+                            dxsum=gref(dxsum) if dxsum is not None else None)
 
         self._glin_wgrad(b.logits, b.lnf, "wte.weight", Gn, R, n_out=V)
         self._glin_dgrad(b.logits, "wte.weight", b.dln, g0, Gn, R, n_in=V)
-        for j in range(Gn):
-            ln_b(j, b.dln, b.x[L], "ln_f", stf, dxsum=gs[j][f"h.{L - 1}.c_proj.bias"])
+        ln_b(b.dln, b.x[L], "ln_f", stf, dxsum=f"h.{L - 1}.c_proj.bias")
         for l in reversed(range(L)):
             p = f"h.{l}."
             st1, st2 = b.stats[2 * l], b.stats[2 * l + 1]
             self._glin_wgrad(b.dres, b.act[l], p + "c_proj.weight", Gn, R)
             self._glin_dgrad(b.dres, p + "c_proj.weight", b.dact, g0, Gn, R)
-            for j in range(Gn):
-                nn_ops.gelu_bwd_colsum(b.fc[l][rows[j]], b.dact[rows[j]], b.dact[rows[j]],
-                                       gs[j][p + "c_fc.bias"])
+            nn_ops.gelu_bwd_colsum_g(b.fc[l], b.dact, b.dact, gref(p + "c_fc.bias"), Gn)
             self._glin_wgrad(b.dact, b.ln2[l], p + "c_fc.weight", Gn, R)
             self._glin_dgrad(b.dact, p + "c_fc.weight", b.dln, g0, Gn, R)
-            for j in range(Gn):
-                ln_b(j, b.dln, b.x_mid[l], p + "ln_2", st2, dres=b.dres,
-                     dxsum=gs[j][p + "attn.c_proj.bias"])
+            ln_b(b.dln, b.x_mid[l], p + "ln_2", st2, dres=b.dres, dxsum=p + "attn.c_proj.bias")
             self._glin_wgrad(b.dres, b.att[l], p + "attn.c_proj.weight", Gn, R)
             self._glin_dgrad(b.dres, p + "attn.c_proj.weight", b.datt, g0, Gn, R)
             attn_ops.causal_attention_bwd(b.qkv[l], b.att[l], b.lse[l], b.datt, b.dqkv,
                                           b.attn_scratch, b.batch, b.seq, m.n_head)
-            for j in range(Gn):
-                nn_ops.colsum(b.dqkv[rows[j]], gs[j][p + "attn.c_attn.bias"])
+            nn_ops.colsum_g(b.dqkv, gref(p + "attn.c_attn.bias"), Gn)
             self._glin_wgrad(b.dqkv, b.ln1[l], p + "attn.c_attn.weight", Gn, R)
             self._glin_dgrad(b.dqkv, p + "attn.c_attn.weight", b.dln, g0, Gn, R)
-            for j in range(Gn):
-                ln_b(j, b.dln, b.x[l], p + "ln_1", st1, dres=b.dres,
-                     dxsum=gs[j][f"h.{l - 1}.c_proj.bias"] if l > 0 else None)
+            ln_b(b.dln, b.x[l], p + "ln_1", st1, dres=b.dres,
+                 dxsum=f"h.{l - 1}.c_proj.bias" if l > 0 else None)
         for j in range(Gn):
             nn_ops.embed_bwd(inp[j * nb : (j + 1) * nb], b.dres[rows[j]], gs[j]["wte.weight"],
                              gs[j]["wpe.weight"], nb, b.seq)

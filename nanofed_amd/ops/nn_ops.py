@@ -34,6 +34,10 @@ _SIGS = {
     "nf_colsum_chunks": ([], I),
     "nf_colsum": ([P, P, P, I, I, L, P], I),
     "nf_ce_fwd_bwd": ([P, P, P, P, I, I, L, FL, P], I),
+    "nf_ln_fwd_g": ([P, P, P, P, P, P, P, P, I, I, I, FL, L, P], I),
+    "nf_ln_bwd_g": ([P, P, P, P, P, P, P, P, P, P, P, I, I, I, L, L, P], I),
+    "nf_colsum_g": ([P, P, P, I, I, I, L, L, P], I),
+    "nf_gelu_bwd_colsum_g": ([P, P, P, P, P, I, I, I, L, P], I),
     "nf_sgd_step_bf16g": ([P, P, P, L, FL, FL, P], I),
 }
 
@@ -265,3 +269,61 @@ def sgd_step_bf16g(p: torch.Tensor, g: torch.Tensor, shadow: torch.Tensor, lr: f
     else:
         p.sub_(lr * (g.float() + weight_decay * p))
         shadow.copy_(p.to(torch.bfloat16))
+
+
+# -- grouped variants: G clients' rows stacked in the matrices, per-client vectors at a fixed
+#    distance from each other (rows of the bf16 parameter copy / the gradient buffer) ---------
+
+def ln_fwd_g(x: torch.Tensor, gamma, beta, y: torch.Tensor, mean: torch.Tensor,
+             rstd: torch.Tensor, G: int, delta: torch.Tensor | None = None,
+             x_out: torch.Tensor | None = None, eps: float = 1e-5) -> None:
+    """``ln_fwd`` for G groups of ``x.shape[0] / G`` rows; ``gamma`` / ``beta`` are
+    ``group_ops.Ref``s: group g's vector lies ``stride`` elements after group g - 1's."""
+    RT, C = x.shape
+    if RT % G or gamma.stride != beta.stride:
+        raise DeviceError("ln_fwd_g: rows must split evenly over the groups")
+    library.check(_fn("nf_ln_fwd_g")(_p(x), _p(delta), _p(x_out), gamma.ptr, beta.ptr, _p(y),
+                                     _p(mean), _p(rstd), G, RT // G, C, eps, gamma.stride,
+                                     library.stream_ptr(x.device)), "ln_fwd_g")
+
+
+def ln_bwd_g(dy: torch.Tensor, x: torch.Tensor, gamma, mean: torch.Tensor, rstd: torch.Tensor,
+             dx: torch.Tensor, dgamma, dbeta, G: int, dres: torch.Tensor | None = None,
+             dxsum=None) -> None:
+    """``ln_bwd`` for G groups; ``gamma`` is a ``Ref`` into the parameter copy, ``dgamma``
+    / ``dbeta`` / ``dxsum`` are ``Ref``s into one gradient buffer."""
+    RT, C = x.shape
+    if RT % G or dgamma.stride != dbeta.stride or (dxsum is not None and dxsum.stride != dgamma.stride):
+        raise DeviceError("ln_bwd_g: inconsistent group layout")
+    nb = int(_fn("nf_ln_bwd_blocks")(RT // G))
+    ws = _workspace(x.device, G * nb * 3 * C)
+    library.check(_fn("nf_ln_bwd_g")(_p(dy), _p(x), gamma.ptr, _p(mean), _p(rstd), _p(dres), _p(dx),
+                                     dgamma.ptr, dbeta.ptr,
+                                     dxsum.ptr if dxsum is not None else c_void_p(0), _p(ws), G,
+                                     RT // G, C, gamma.stride, dgamma.stride,
+                                     library.stream_ptr(x.device)), "ln_bwd_g")
+
+
+def colsum_g(m: torch.Tensor, out, G: int) -> None:
+    """Per-group column sums of a contiguous-row bf16 matrix into ``out`` (a ``Ref``)."""
+    RT, N = m.shape
+    if RT % G or m.stride(1) != 1:
+        raise DeviceError("colsum_g: rows must split evenly over the groups")
+    chunks = int(_fn("nf_colsum_chunks")())
+    ws = _workspace(m.device, G * chunks * N)
+    library.check(_fn("nf_colsum_g")(_p(m), out.ptr, _p(ws), G, RT // G, N, m.stride(0), out.stride,
+                                     library.stream_ptr(m.device)), "colsum_g")
+
+
+def gelu_bwd_colsum_g(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, dbias, G: int) -> None:
+    """``gelu_bwd_colsum`` with one bias gradient per group (``dbias`` a ``Ref``)."""
+    RT, N = x.shape
+    if RT % G:
+        raise DeviceError("gelu_bwd_colsum_g: rows must split evenly over the groups")
+    _need(x, torch.bfloat16, "x")
+    _need(dy, torch.bfloat16, "dy")
+    chunks = int(_fn("nf_colsum_chunks")())
+    ws = _workspace(x.device, G * chunks * N)
+    library.check(_fn("nf_gelu_bwd_colsum_g")(_p(x), _p(dy), _p(dx), dbias.ptr, _p(ws), G, RT // G,
+                                              N, dbias.stride, library.stream_ptr(x.device)),
+                  "gelu_bwd_colsum_g")
