@@ -453,6 +453,28 @@ int nf_bn_fwd(const void* x, const void* res, void* y, const float* gamma, const
                       C, relu, momentum, eps, pre_blocks, 0, s);
 }
 
+// Inference: y = relu((x - stats[0]) stats[1] gamma + beta (+ res)) with given per-channel
+// mean (stats[0][c]) and 1/std (stats[1][c]) - the apply pass of nf_bn_fwd alone.
+int nf_bn_apply(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                const float* stats, long R, int C, int relu, hipStream_t s) {
+    if (lanes_per_row(C) == 0 || R <= 0) return -1;
+    if (!al16(x) || !al16(y) || (res != nullptr && !al16(res))) return -2;
+    const long n8 = R * C / 8;
+    const dim3 grid(grid_cap(n8, 1), 1), block(256);
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* rp = static_cast<const bf16*>(res);
+    bf16* yp = static_cast<bf16*>(y);
+    if (relu && res != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, 0L);
+    else if (relu)
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, 0L);
+    else if (res != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, 0L);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, xp, rp, stats, gamma, beta, yp, n8, C, 0L);
+    return static_cast<int>(hipGetLastError());
+}
+
 // dgamma / dbeta (fp32) are overwritten.  dres (may be null) receives the
 // gradient of the residual input.  workspace: nf_bn_workspace_floats(C) + 2*C floats.
 int nf_bn_bwd(const void* dy, const void* y, const void* x, const float* stats,

@@ -26,6 +26,7 @@ _SIGS = {
     "nf_bn_workspace_floats": ([I], I),
     "nf_bn_fwd": ([P, P, P, P, P, P, P, P, P, L, I, I, FL, FL, I, P], I),
     "nf_bn_bwd": ([P, P, P, P, P, P, P, P, P, P, L, I, I, P], I),
+    "nf_bn_apply": ([P, P, P, P, P, P, L, I, I, P], I),
 }
 _fns: dict[str, object] = {}
 
@@ -52,6 +53,8 @@ def channels_supported(channels: int) -> bool:
 
 
 def fused_path_applies(x: torch.Tensor, training: bool, residual: torch.Tensor | None) -> bool:
+    """Layout / dtype conditions of the kernels (training: also called with the module's
+    mode; the inference path passes True and checks the mode itself)."""
     if not (training and x.device.type == "cuda" and x.dtype == torch.bfloat16 and x.dim() == 4):
         return False
     if not x.is_contiguous(memory_format=torch.channels_last):
@@ -135,7 +138,25 @@ def batch_norm_act(bn: nn.BatchNorm2d, x: torch.Tensor, residual: torch.Tensor |
                 bn.num_batches_tracked.add_(1)
         return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    residual, relu, float(bn.momentum), float(bn.eps), partials)
+    if (not bn.training and bn.affine and bn.track_running_stats and not torch.is_grad_enabled()
+            and fused_path_applies(x, True, residual)):
+        return _inference(bn, x, residual, relu)
     out = bn(x)
     if residual is not None:
         out = out + residual
     return F.relu(out) if relu else out
+
+
+def _inference(bn: nn.BatchNorm2d, x: torch.Tensor, residual: torch.Tensor | None,
+               relu: bool) -> torch.Tensor:
+    """Evaluation mode without gradients: the apply kernel alone, on the running statistics."""
+    n, c, h, w = x.shape
+    stats = torch.stack((bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)))
+    y = torch.empty_like(x)
+    library.check(
+        _fn("nf_bn_apply")(_p(x), _p(residual), _p(y), _p(bn.weight.detach().float().contiguous()),
+                           _p(bn.bias.detach().float().contiguous()), _p(stats.contiguous()),
+                           n * h * w, c, int(relu), library.stream_ptr(x.device)),
+        "bn_apply",
+    )
+    return y

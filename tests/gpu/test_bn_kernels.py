@@ -77,3 +77,32 @@ def test_fallbacks_keep_pytorch_semantics():
     assert batch_norm_act(bn, xb).shape == x.shape
     odd = torch.randn(2, 24, 4, 4, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert not fused_path_applies(odd, True, None)
+
+
+@pytest.mark.parametrize("with_res,relu", [(True, True), (False, True), (False, False)])
+def test_inference_mode_uses_the_running_statistics(with_res, relu):
+    """Evaluation without gradients runs the apply kernel alone; the oracle is
+    F.batch_norm in eval mode on the same inputs in fp32."""
+    torch.manual_seed(11)
+    c, shape = 128, (8, 128, 8, 8)
+    bn = nn.BatchNorm2d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.normal_(0.0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+    bn.eval()
+    x = (torch.randn(shape, device=DEV) * 1.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if with_res else None
+    before = (bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+    with torch.no_grad():
+        y = batch_norm_act(bn, x, residual=res, relu=relu)
+        ref = F.batch_norm(x.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        if with_res:
+            ref = ref + res.float()
+        if relu:
+            ref = F.relu(ref)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=2e-2)
+    assert torch.equal(bn.running_mean, before[0]) and torch.equal(bn.running_var, before[1])
+    assert int(bn.num_batches_tracked) == before[2]
