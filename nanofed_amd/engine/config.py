@@ -85,6 +85,13 @@ class EngineConfig:
     # unmatched masks are removed on device); "none" reduces the plain rows
     secure_agg: str = "none"
     secure_mask_scale: float = 1.0
+    # signed updates (reference: SecurityManager.sign_update / verify_signature,
+    # nanofed/server/validation.py:138-212): every client holds an RSA-2048 key and signs
+    # (round, client id, tree digest of its arena row) with RSA-PSS; before aggregation the
+    # digest of the row as it arrived is recomputed and the signature checked - a row that
+    # fails is left out of the round.  Digests are computed on the device
+    # (ops/digest_ops.py); costs two small host synchronisations per round.
+    sign_updates: bool = False
     # a client that reports later than this many seconds is left out of the round
     # (reference: CoordinatorConfig.round_timeout); 0 = wait for everybody
     round_timeout_s: float = 0.0

@@ -114,7 +114,9 @@ class FaultPlan:
     raised once in the middle of round r, the way a HIP or RCCL error would
     surface, on every rank - or only on the ranks in ``fail_ranks`` when that is
     set; ``stall[r]`` = {rank: seconds that rank sleeps inside round r} (a hung
-    peer, for watchdog drills)."""
+    peer, for watchdog drills); ``tamper[r]`` = client ids whose update is altered
+    after the client signed it (one value changed on the way to the aggregator; it
+    takes ``EngineConfig.sign_updates`` to notice)."""
 
     drop: dict[int, set[int]] = field(default_factory=dict)
     poison: dict[int, set[int]] = field(default_factory=dict)
@@ -123,6 +125,7 @@ class FaultPlan:
     fail: dict[int, str] = field(default_factory=dict)
     fail_ranks: set[int] | None = None
     stall: dict[int, dict[int, float]] = field(default_factory=dict)
+    tamper: dict[int, set[int]] = field(default_factory=dict)
 
 
 def clients_of_rank(num_clients: int, world: int, rank: int) -> list[int]:
@@ -308,6 +311,18 @@ class FederatedEngine:
         self._shares: torch.Tensor | None = None
         if cfg.secure_agg == "pairwise":
             self._setup_secure_agg()
+        # signed updates: one key pair per simulated client of this rank; the public
+        # halves are what the aggregating side verifies against
+        self._signers: list = []
+        self.client_public_keys: dict[int, bytes] = {}
+        self.unverified_updates = 0
+        if cfg.sign_updates:
+            from nanofed_amd.crypto.backend import RSAKey
+
+            self._signers = [RSAKey.generate(2048) for _ in self.client_ids]
+            self.client_public_keys = {
+                cid: key.public_pem() for cid, key in zip(self.client_ids, self._signers)
+            }
 
         self._model_manager = None
         self._recovery = None
@@ -489,7 +504,11 @@ class FederatedEngine:
             if failure is None:
                 with timer.phase("local_train"):
                     local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
+                signatures = self._sign_rows(r) if self._signers else None
                 self._inject_faults(r, local)
+                if signatures is not None:
+                    with timer.phase("verify_signatures"):
+                        self._verify_rows(r, signatures, local)
         except Exception as exc:  # noqa: BLE001 - agreed on below, re-raised on every rank
             failure = exc
         if failure is not None and not multi:
@@ -527,7 +546,7 @@ class FederatedEngine:
 
     def _faulty(self, r: int) -> bool:
         f = self.faults
-        return any(r in d for d in (f.drop, f.poison, f.scale, f.delay, f.fail, f.stall))
+        return any(r in d for d in (f.drop, f.poison, f.scale, f.delay, f.fail, f.stall, f.tamper))
 
     def _inject_faults(self, r: int, local: torch.Tensor) -> None:
         cfg = self.cfg
@@ -547,8 +566,49 @@ class FederatedEngine:
                 row.copy_(g + (row - g) * float(f.scale[r][cid]))
             if cid in f.poison.get(r, ()):
                 self.pool[k].data.fill_(float("nan"))
+            if cid in f.tamper.get(r, ()):
+                self.pool[k].data[7] += 0.125  # one value altered after signing
             if cid in f.drop.get(r, ()) or cid in late:
                 local[k, M_VALID] = 0.0
+
+    # -- signed updates ---------------------------------------------------------------
+    @staticmethod
+    def _signing_message(r: int, cid: int, digest: bytes) -> bytes:
+        return b"nanofed-amd/update/v1|" + r.to_bytes(8, "big") + cid.to_bytes(8, "big") + digest
+
+    def _sign_rows(self, r: int) -> list[bytes]:
+        """Client side: every local client signs (round, its id, the tree digest of its
+        arena row) with its private key (RSA-PSS, SHA-256).  Reference:
+        SecurityManager.sign_update, nanofed/server/validation.py:189-194 - there over the
+        serialised tensors, here over a digest computed where the row lies."""
+        from nanofed_amd.ops.digest_ops import row_digests
+
+        digests = row_digests(self.pool.data)
+        return [
+            key.pss_sign(self._signing_message(r, cid, d))
+            for key, cid, d in zip(self._signers, self.client_ids, digests)
+        ]
+
+    def _verify_rows(self, r: int, signatures: list[bytes], local: torch.Tensor) -> None:
+        """Aggregating side: recompute the digest of every row as it arrived and check it
+        against the client's signature and registered public key; a row that fails takes
+        no part in the round (nanofed/server/validation.py:196-207)."""
+        from nanofed_amd.crypto.backend import RSAKey
+        from nanofed_amd.ops.digest_ops import row_digests
+
+        digests = row_digests(self.pool.data)
+        bad = []
+        for k, (cid, d, sig) in enumerate(zip(self.client_ids, digests, signatures)):
+            key = RSAKey.from_public_pem(self.client_public_keys[cid])
+            if not key.pss_verify(self._signing_message(r, cid, d), sig):
+                bad.append(k)
+        if bad:
+            self.unverified_updates += len(bad)
+            self.logger.warning(
+                f"round {r}: signature check failed for clients "
+                f"{[self.client_ids[k] for k in bad]}; their updates are left out"
+            )
+            local[torch.tensor(bad, device=local.device), M_VALID] = 0.0
 
     # steps 3-7
     def _tail(self, local: torch.Tensor | None, failed: bool, eager: bool) -> None:
