@@ -68,9 +68,14 @@ def info() -> None:
               help="checkpoint every completed round and roll back on recoverable failures")
 @click.option("--resume", is_flag=True, help="continue from the newest model version in --base-dir")
 @click.option("--phases", is_flag=True, help="print the HIP-event timing of the round phases")
+@click.option("--zscore", default=0.0, help="leave out updates whose norm is this many sigmas off (0 = off)")
+@click.option("--secure-agg", type=click.Choice(["none", "pairwise"]), default="none",
+              help="blind client rows with pairwise masks before the reduce")
+@click.option("--sign-updates", is_flag=True, help="clients sign their updates (RSA-PSS), verified before aggregation")
 def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_client, lr,
         partition, alpha, dp_noise, dp_clip, backend, base_dir, seq_len, min_clients,
-        max_update_norm, checkpoint_rounds, resume, phases) -> None:
+        max_update_norm, checkpoint_rounds, resume, phases, zscore, secure_agg,
+        sign_updates) -> None:
     """Federated rounds on the device plane (launch under torch.distributed.run for multi-GPU)."""
     from nanofed_amd.engine import DPConfig, EngineConfig, FederatedEngine
     from nanofed_amd.parallel import Communicator
@@ -83,7 +88,8 @@ def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_c
         batch_size=batch_size, samples_per_client=samples_per_client, learning_rate=lr,
         partition=partition, dirichlet_alpha=alpha, backend=backend, seq_len=seq_len,
         min_clients=min_clients, max_update_norm=max_update_norm,
-        checkpoint_rounds=checkpoint_rounds,
+        checkpoint_rounds=checkpoint_rounds, zscore_threshold=zscore, secure_agg=secure_agg,
+        sign_updates=sign_updates,
         dp=DPConfig(max_gradient_norm=dp_clip, noise_multiplier=dp_noise) if dp_noise > 0 else None,
     )
     comm = Communicator.from_env()
