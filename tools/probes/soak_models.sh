@@ -1,5 +1,5 @@
 set -o pipefail
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 mkdir -p gpurun_out
 echo "== resnet 30 rounds"; timeout -k 10 300 python -u benchmarks/run_configs.py resnet18 --rounds 30 --warmup 2 2> gpurun_out/soak_resnet.err | tee gpurun_out/soak_resnet.json || { tail -20 gpurun_out/soak_resnet.err; exit 1; }
 echo "== gpt2 10 rounds"; timeout -k 10 300 python -u benchmarks/run_configs.py gpt2_125m --rounds 10 --warmup 1 2> gpurun_out/soak_gpt2.err | tee gpurun_out/soak_gpt2.json || { tail -20 gpurun_out/soak_gpt2.err; exit 1; }
