@@ -88,6 +88,8 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1)
     t256 = (-(-M // 256)) * (-(-N // 256)) * batch
     if t256 >= 224 and ksteps >= 32 and min(M, N) >= 2048:
         return GEO_256        # enough 256 x 256 tiles for every CU, a long K loop, both sides wide
+    if layout == TN and t256 >= 224 and ksteps >= 32 and max(M, N) >= 16384 and min(M, N) >= 512:
+        return GEO_256        # the LM head's weight gradient: one very long side (344 vs 401 us)
     if t256 >= 1024 and layout == NT:
         return GEO_256x128    # very wide outputs with a short K loop (the LM head)
     if layout == NT and N % 192 == 0:

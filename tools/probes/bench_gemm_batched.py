@@ -14,12 +14,15 @@ torch.cuda.set_device(0)
 bf = torch.bfloat16
 M, G = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 8
 shapes = {"c_attn": (2304, 768), "attn_proj": (768, 768), "c_fc": (3072, 768), "mlp_proj": (768, 3072)}
+if len(sys.argv) > 2 and sys.argv[2] == "lm_head":
+    shapes = {"lm_head": (50257, 768)}
 tot_single = tot_batched = 0.0
 for name, (N, K) in shapes.items():
     x = torch.randn(G, M, K, device="cuda").to(bf)
     w = (torch.randn(G, N, K, device="cuda") * 0.05).to(bf)
-    y = torch.empty(G, M, N, dtype=bf, device="cuda")
-    dy = (torch.randn(G, M, N, device="cuda") * 0.1).to(bf)
+    LD = (N + 63) // 64 * 64
+    y = torch.empty(G, M, LD, dtype=bf, device="cuda")
+    dy = (torch.randn(G, M, LD, device="cuda") * 0.1).to(bf)
     dx = torch.empty(G, M, K, dtype=bf, device="cuda")
     dw = torch.empty(G, N, K, dtype=bf, device="cuda")
     slabs = torch.empty(max(go.gemm_slab_floats(M, N, K, 0, G), go.gemm_slab_floats(M, K, N, 1, G),
@@ -27,27 +30,27 @@ for name, (N, K) in shapes.items():
 
     def single():
         for g in range(G):
-            gemm_ops.linear_fwd(x[g], w[g], None, y[g])
+            gemm_ops.linear_fwd(x[g], w[g], None, y[g][:, :N])
 
     def single_d():
         for g in range(G):
-            gemm_ops.linear_dgrad(dy[g], w[g], dx[g])
+            gemm_ops.linear_dgrad(dy[g][:, :N], w[g], dx[g])
 
     def single_w():
         for g in range(G):
-            gemm_ops.linear_wgrad(dy[g], x[g], dw[g])
+            gemm_ops.linear_wgrad(dy[g][:, :N], x[g], dw[g])
 
     def batched():
-        go.gemm_batched(0, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, N, G,
-                        M * K, N * K, M * N, slabs, go._stream(y))
+        go.gemm_batched(0, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, LD, G,
+                        M * K, N * K, M * LD, slabs, go._stream(y))
 
     def batched_d():
-        go.gemm_batched(1, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, K, N, N, K, K, G,
-                        M * N, N * K, M * K, slabs, go._stream(y))
+        go.gemm_batched(1, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, K, N, LD, K, K, G,
+                        M * LD, N * K, M * K, slabs, go._stream(y))
 
     def batched_w():
-        go.gemm_batched(2, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, M, N, K, K, G,
-                        M * N, M * K, N * K, slabs, go._stream(y))
+        go.gemm_batched(2, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, M, LD, K, K, G,
+                        M * LD, M * K, N * K, slabs, go._stream(y))
 
     row = {}
     for tag, a, b in (("fwd", single, batched), ("dgrad", single_d, batched_d), ("wgrad", single_w, batched_w)):
