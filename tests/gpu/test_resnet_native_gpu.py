@@ -357,3 +357,19 @@ def test_faults_and_rollback_leave_the_trainer_consistent(tmp_path):
     assert ra[0].num_clients == 2 and ra[1].num_clients == 2
     assert torch.equal(a.global_arena.data, b.global_arena.data)
     assert int(b.global_state_dict()["bn1.num_batches_tracked"]) == 8  # 4 rounds of 2 steps
+
+
+def test_groups_larger_than_the_launch_limit_are_stepped_in_chunks(monkeypatch):
+    """Three clients with at most two per launch: chunks (0, 2) and (2, 1) must train the
+    models of the single launch of three up to bf16 noise (the group size picks the tile)."""
+    from nanofed_amd.engine import resnet_native
+
+    whole = _engine("native", clients=3, samples=64)
+    ra = whole.run(1)
+    monkeypatch.setattr(resnet_native, "MAX_GROUP", 2)
+    split = _engine("native", clients=3, samples=64)
+    rb = split.run(1)
+    assert set(split.trainer._ggraphs) == {(0, 2), (2, 1)}
+    assert set(whole.trainer._ggraphs) == {(0, 3)}
+    assert rb[0].agg_metrics["loss"] == pytest.approx(ra[0].agg_metrics["loss"], rel=2e-2)
+    assert _rel(split.global_arena.data, whole.global_arena.data) < 0.02
