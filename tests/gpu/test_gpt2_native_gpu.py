@@ -141,15 +141,17 @@ def test_grouped_steps_train_the_same_model_as_client_after_client(monkeypatch):
     from nanofed_amd.engine import gpt2_native
 
     outs = []
-    for group in (0, 8):
+    for group in (0, 8, 2):   # client after client, one group of three, chunks of 2 + 1
         monkeypatch.setattr(gpt2_native, "GROUP", group)
         eng = _engine(num_clients=3, samples_per_client=8, learning_rate=0.1)
-        assert eng.trainer.group == (3 if group else 0)
+        assert eng.trainer.group == min(group, 3)
         reps = [eng.run_round() for _ in range(2)]
         torch.cuda.synchronize()
         outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reps],
                      [r.agg_metrics["accuracy"] for r in reps]))
-    (a, la, ca), (b, lb, cb) = outs
+    (a, la, ca), (b, lb, cb), (c, lc, _) = outs
+    assert lc == pytest.approx(la, rel=2e-3)
+    assert float((a - c).norm() / a.norm()) < 2e-3
     assert lb == pytest.approx(la, rel=2e-3)
     assert cb == pytest.approx(ca, abs=5e-3)
     rel = float((a - b).norm() / a.norm())
