@@ -1,7 +1,8 @@
 // SHA-256 of fixed-size chunks of arena rows: the leaves of the tree digest that a client
 // signs and the aggregating side verifies (ops/digest_ops.py).  The reference signs the
 // serialised update on the host (nanofed/server/validation.py:138-212); here only
-// 32 bytes per 4 KiB chunk leave the device and the host hashes those.
+// 32 bytes per chunk (1 KiB, or 64 KiB for rows beyond 16 MiB) leave the device and the
+// host hashes those.
 //
 // One thread hashes one chunk (a whole number of 64-byte blocks) with the standard
 // padding for its length; thread i of a row reads bytes [i * chunk, (i + 1) * chunk).

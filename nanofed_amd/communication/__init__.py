@@ -1,5 +1,13 @@
 from . import codec
-from .http import HTTPClient, HTTPServer
+from .http import ClientEndpoints, HTTPClient, HTTPServer, ServerEndpoints
 from .innode import InNodeClient, InNodeServer
 
-__all__ = ["HTTPClient", "HTTPServer", "InNodeClient", "InNodeServer", "codec"]
+__all__ = [
+    "HTTPClient",
+    "HTTPServer",
+    "ClientEndpoints",
+    "ServerEndpoints",
+    "InNodeClient",
+    "InNodeServer",
+    "codec",
+]

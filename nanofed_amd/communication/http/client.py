@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import asyncio
 from dataclasses import dataclass
-from typing import Any
+from typing import Any, TypeAlias
 
 import aiohttp
 import numpy as np
@@ -22,6 +22,10 @@ from nanofed_amd.communication import codec
 from nanofed_amd.core import ModelProtocol, NanoFedError
 from nanofed_amd.trainer.base import TrainingMetrics
 from nanofed_amd.utils import Logger, get_current_time, log_exec
+
+# what a wire body may hold for one parameter / for a whole model
+TensorLike: TypeAlias = torch.Tensor | list[float] | list[list[float]] | float | int
+ModelState: TypeAlias = dict[str, list[float] | list[list[float]]]
 
 
 @dataclass(slots=True, frozen=True)

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import asyncio
 from dataclasses import dataclass
-from typing import TYPE_CHECKING, Any
+from typing import TYPE_CHECKING, Any, TypeAlias
 
 import numpy as np
 import torch
@@ -37,6 +37,10 @@ if TYPE_CHECKING:
 _REQUIRED_UPDATE_KEYS = frozenset(
     {"client_id", "round_number", "model_state", "metrics", "timestamp"}
 )
+
+# what a wire body may hold for one parameter / for a whole model
+TensorLike: TypeAlias = torch.Tensor | list[float] | list[list[float]] | float | int
+ModelState: TypeAlias = dict[str, list[float] | list[list[float]]]
 
 
 @dataclass(slots=True, frozen=True)

@@ -45,18 +45,18 @@ class PrivacyConfig(BaseModel):
 
     @field_validator("epsilon")
     @classmethod
-    def _epsilon_in_range(cls, value: float) -> float:
-        if not (C.MIN_EPSILON <= value <= C.MAX_EPSILON):
+    def validate_epsilon(cls, v: float) -> float:
+        if not (C.MIN_EPSILON <= v <= C.MAX_EPSILON):
             raise ValueError(
                 f"epsilon must be between {C.MIN_EPSILON} and {C.MAX_EPSILON}"
             )
-        return value
+        return v
 
     @field_validator("delta")
     @classmethod
-    def _delta_in_range(cls, value: float) -> float:
-        if not (C.MIN_DELTA <= value <= C.MAX_DELTA):
+    def validate_delta(cls, v: float) -> float:
+        if not (C.MIN_DELTA <= v <= C.MAX_DELTA):
             raise ValueError(
                 f"delta must be between {C.MIN_DELTA} and {C.MAX_DELTA}"
             )
-        return value
+        return v

@@ -59,6 +59,9 @@ class ModelValidator(Protocol):
     def validate_statistics(
         self, update: ModelUpdate, reference_updates: Sequence[ModelUpdate]
     ) -> ValidationResult: ...
+    def validate_signature(
+        self, update: ModelUpdate, public_key: bytes
+    ) -> ValidationResult: ...
 
 
 def _global_norm(state: dict[str, torch.Tensor]) -> float:
