@@ -41,8 +41,11 @@ def test_the_check_notices_missing_names_and_changed_signatures(tool, surface):
     broken["server"]["all"].append("NoSuchAggregator")
     fedavg = broken["server.aggregator.fedavg"]["classes"]["FedAvgAggregator"]
     fedavg["methods"]["aggregate"]["pos"].reverse()
-    fedavg["methods"]["no_such_method"] = {"pos": ["self"], "kw": [], "var": False, "varkw": False}
+    fedavg["methods"]["no_such_method"] = {"pos": ["self"], "kw": [], "var": False, "varkw": False,
+                                           "defaults": {}}
     broken["utils.dates"]["functions"]["get_current_time"]["kw"].append("no_such_keyword")
+    broken["privacy.constants"]["values"]["MAX_EPSILON"] = 11.0
+    broken["trainer.base"]["classes"]["TrainingConfig"]["values"]["max_batches"] = 7
     broken["no.such.module"] = {"all": None, "classes": {}, "functions": {}, "names": []}
     problems = "\n".join(tool.compare(broken))
     assert "NoSuchAggregator" in problems
@@ -50,6 +53,8 @@ def test_the_check_notices_missing_names_and_changed_signatures(tool, surface):
     assert "no_such_method" in problems
     assert "get_current_time" in problems
     assert "no.such.module" in problems
+    assert "MAX_EPSILON" in problems
+    assert "TrainingConfig.max_batches" in problems
 
 
 def test_parser_reads_signatures_without_importing(tool, tmp_path):
@@ -70,7 +75,11 @@ def test_parser_reads_signatures_without_importing(tool, tmp_path):
     )
     info = tool.parse_module(str(src))
     assert info["all"] == ["fn", "Cls"] and info["names"] == ["LIMIT", "DEFAULT"]
-    assert info["functions"]["fn"] == {"pos": ["a", "b"], "kw": ["c"], "var": False, "varkw": True}
+    assert info["functions"]["fn"] == {"pos": ["a", "b"], "kw": ["c"], "var": False, "varkw": True,
+                                       "defaults": {"b": 1, "c": 2}}
+    assert info["values"] == {"LIMIT": 3, "DEFAULT": 4}
     assert info["classes"]["Cls"]["fields"] == ["x"]
+    assert info["classes"]["Cls"]["values"] == {"x": 0}
     assert info["classes"]["Cls"]["methods"] == {
-        "m": {"pos": ["self", "p"], "kw": [], "var": False, "varkw": False}, "q": None}
+        "m": {"pos": ["self", "p"], "kw": [], "var": False, "varkw": False, "defaults": {}},
+        "q": None}

@@ -28,13 +28,49 @@ if ROOT not in sys.path:
 FIXTURE = os.path.join(ROOT, "tests", "fixtures", "reference_api_surface.json")
 
 
+_NO_LITERAL = object()
+
+
+def _literal(node: ast.AST | None):
+    """The value of a literal expression (numbers, strings, None, booleans, containers of
+    those), or ``_NO_LITERAL``."""
+    if node is None:
+        return _NO_LITERAL
+    if isinstance(node, ast.Call) and getattr(node.func, "id", getattr(node.func, "attr", "")) in (
+        "Field", "field"
+    ):  # pydantic / dataclasses field declarations: their literal default
+        for kw in node.keywords:
+            if kw.arg == "default":
+                return _literal(kw.value)
+        if node.args and getattr(node.func, "id", getattr(node.func, "attr", "")) == "Field":
+            return _literal(node.args[0])
+        return _NO_LITERAL
+    try:
+        value = ast.literal_eval(node)
+    except (ValueError, TypeError, SyntaxError, MemoryError, RecursionError):
+        return _NO_LITERAL
+    try:
+        return json.loads(json.dumps(value))  # what the fixture can hold (tuples -> lists)
+    except (TypeError, ValueError):
+        return _NO_LITERAL
+
+
 def _params(fn: ast.FunctionDef | ast.AsyncFunctionDef) -> dict:
     a = fn.args
+    pos = a.posonlyargs + a.args
+    defaults: dict = {}
+    for arg, d in zip(pos[len(pos) - len(a.defaults):], a.defaults):
+        if (v := _literal(d)) is not _NO_LITERAL:
+            defaults[arg.arg] = v
+    for arg, d in zip(a.kwonlyargs, a.kw_defaults):
+        if (v := _literal(d)) is not _NO_LITERAL:
+            defaults[arg.arg] = v
     return {
-        "pos": [x.arg for x in a.posonlyargs + a.args],
+        "pos": [x.arg for x in pos],
         "kw": [x.arg for x in a.kwonlyargs],
         "var": a.vararg is not None,
         "varkw": a.kwarg is not None,
+        "defaults": defaults,
     }
 
 
@@ -64,7 +100,7 @@ def _public(name: str) -> bool:
 def parse_module(path: str) -> dict:
     with open(path, encoding="utf-8") as fh:
         tree = ast.parse(fh.read(), filename=path)
-    out: dict = {"all": None, "classes": {}, "functions": {}, "names": []}
+    out: dict = {"all": None, "classes": {}, "functions": {}, "names": [], "values": {}}
     for node in tree.body:
         if isinstance(node, ast.Assign):
             for t in node.targets:
@@ -74,24 +110,32 @@ def parse_module(path: str) -> dict:
                                       if isinstance(e, ast.Constant) and isinstance(e.value, str)]
                     elif _public(t.id) and len(t.id) > 1:  # T, P, R: type variables
                         out["names"].append(t.id)
+                        if (v := _literal(node.value)) is not _NO_LITERAL:
+                            out["values"][t.id] = v
         elif isinstance(node, ast.AnnAssign) and isinstance(node.target, ast.Name):
             if _public(node.target.id):
                 out["names"].append(node.target.id)
+                if (v := _literal(node.value)) is not _NO_LITERAL:
+                    out["values"][node.target.id] = v
         elif isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef)) and _public(node.name):
             out["functions"][node.name] = _params(node)
         elif isinstance(node, ast.ClassDef) and _public(node.name):
-            methods, fields = {}, []
+            methods, fields, values = {}, [], {}
             for item in node.body:
                 if isinstance(item, (ast.FunctionDef, ast.AsyncFunctionDef)) and _public(item.name):
                     methods[item.name] = None if _is_property(item) else _params(item)
                 elif isinstance(item, ast.AnnAssign) and isinstance(item.target, ast.Name):
                     if _public(item.target.id):
                         fields.append(item.target.id)
+                        if (v := _literal(item.value)) is not _NO_LITERAL:
+                            values[item.target.id] = v
                 elif isinstance(item, ast.Assign):
                     for t in item.targets:
                         if isinstance(t, ast.Name) and _public(t.id):
                             fields.append(t.id)
-            out["classes"][node.name] = {"methods": methods, "fields": fields,
+                            if (v := _literal(item.value)) is not _NO_LITERAL:
+                                values[t.id] = v
+            out["classes"][node.name] = {"methods": methods, "fields": fields, "values": values,
                                          "dataclass": _is_dataclass(node)}
     return out
 
@@ -113,8 +157,10 @@ def _own_params(obj) -> dict | None:
         sig = inspect.signature(obj)
     except (TypeError, ValueError):
         return None
-    out: dict = {"pos": [], "kw": [], "var": False, "varkw": False}
+    out: dict = {"pos": [], "kw": [], "var": False, "varkw": False, "defaults": {}}
     for p in sig.parameters.values():
+        if p.default is not p.empty:
+            out["defaults"][p.name] = p.default
         if p.kind is p.VAR_POSITIONAL:
             out["var"] = True
         elif p.kind is p.VAR_KEYWORD:
@@ -139,6 +185,59 @@ def _compatible(ref: dict, own: dict | None) -> bool:
     return own["varkw"] or all(k in accepted for k in ref["kw"])
 
 
+def _plain(value):
+    """A value of this package in the form the fixture holds literals (enums by value)."""
+    import enum
+    from pathlib import PurePath
+
+    if isinstance(value, enum.Enum):
+        value = value.value
+    if isinstance(value, PurePath):
+        value = str(value)
+    try:
+        return json.loads(json.dumps(value))
+    except (TypeError, ValueError):
+        return _NO_LITERAL
+
+
+def _same(ref, own) -> bool:
+    own = _plain(own)
+    if own is _NO_LITERAL:
+        return True  # not comparable as a literal (objects, factories)
+    if isinstance(ref, (int, float)) and isinstance(own, (int, float)) \
+            and not isinstance(ref, bool) and not isinstance(own, bool):
+        return float(ref) == float(own)
+    return ref == own
+
+
+def _default_problems(where: str, ref: dict, own: dict | None) -> list[str]:
+    if own is None:
+        return []
+    out = []
+    for arg, value in ref.get("defaults", {}).items():
+        if arg not in own["defaults"]:
+            if arg in own["pos"] or arg in own["kw"]:
+                out.append(f"{where}: {arg} has default {value!r} in the reference, none here")
+        elif not _same(value, own["defaults"][arg]):
+            out.append(f"{where}: default of {arg} is {own['defaults'][arg]!r}, "
+                       f"the reference's {value!r}")
+    return out
+
+
+def _field_default(cls, field: str):
+    import dataclasses
+
+    model_fields = getattr(cls, "model_fields", None) or {}
+    if field in model_fields:
+        info = model_fields[field]
+        return _NO_LITERAL if info.default_factory is not None else info.default
+    if dataclasses.is_dataclass(cls):
+        for f in dataclasses.fields(cls):
+            if f.name == field:
+                return _NO_LITERAL if f.default is dataclasses.MISSING else f.default
+    return getattr(cls, field, _NO_LITERAL)
+
+
 def _show(sig: dict | None) -> str:
     if sig is None:
         return "?"
@@ -161,12 +260,17 @@ def compare(surface: dict, package: str = "nanofed_amd") -> list[str]:
         for n in info["names"]:
             if not hasattr(module, n):
                 problems.append(f"{name}: name {n} missing")
+        for n, value in info.get("values", {}).items():
+            if hasattr(module, n) and not _same(value, getattr(module, n)):
+                problems.append(f"{name}.{n} is {getattr(module, n)!r}, the reference's {value!r}")
         for fn, params in info["functions"].items():
             obj = getattr(module, fn, None)
             if obj is None:
                 problems.append(f"{name}: function {fn} missing")
             elif not _compatible(params, _own_params(obj)):
                 problems.append(f"{name}.{fn}: {_show(params)} vs {_show(_own_params(obj))}")
+            else:
+                problems += _default_problems(f"{name}.{fn}", params, _own_params(obj))
         for cn, cinfo in info["classes"].items():
             cls = getattr(module, cn, None)
             if cls is None:
@@ -181,6 +285,8 @@ def compare(surface: dict, package: str = "nanofed_amd") -> list[str]:
                 own = _own_params(getattr(cls, mn))
                 if not _compatible(params, own):
                     problems.append(f"{name}.{cn}.{mn}: {_show(params)} vs {_show(own)}")
+                else:
+                    problems += _default_problems(f"{name}.{cn}.{mn}", params, own)
             if cinfo.get("dataclass") and "__init__" not in cinfo["methods"]:
                 # positional construction: the generated __init__ takes the fields in order
                 own = _own_params(cls)
@@ -188,6 +294,11 @@ def compare(surface: dict, package: str = "nanofed_amd") -> list[str]:
                     if not (own["var"] and own["varkw"]):
                         problems.append(f"{name}.{cn}: constructor takes {_show(own)}, the "
                                         f"reference's fields are {cinfo['fields']}")
+            for field, value in cinfo.get("values", {}).items():
+                own_value = _field_default(cls, field)
+                if own_value is not _NO_LITERAL and not _same(value, own_value):
+                    problems.append(f"{name}.{cn}.{field} defaults to {own_value!r}, "
+                                    f"the reference's {value!r}")
             annotations = {}
             for klass in getattr(cls, "__mro__", ()):
                 annotations.update(getattr(klass, "__annotations__", {}))
