@@ -292,7 +292,7 @@ class FederatedEngine:
         self.pool = ArenaPool(self.layout, len(self.client_ids), self.device)
         self.trainer = self._make_trainer(trainer_factory)
 
-        K, G, W = cfg.num_clients, len(self.client_ids), self.comm.world_size
+        K, W = cfg.num_clients, self.comm.world_size
         f32 = dict(dtype=torch.float32, device=self.device)
         self._K = K
         self._partial = torch.zeros(self.layout.numel, **f32)

@@ -29,7 +29,6 @@ Operations and the reference behaviour they replace:
 
 from __future__ import annotations
 
-import ctypes
 import math
 from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
 from typing import Sequence

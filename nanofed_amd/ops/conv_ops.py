@@ -305,7 +305,7 @@ class _ConvGemm(torch.autograd.Function):
         from . import gemm_ops
 
         w = weight.detach().contiguous(memory_format=CL)
-        o, i, kh, kw = w.shape
+        o, _, kh, kw = w.shape
         b, _, h, wd = x.shape
         ho, wo = _out_size(h, kh, stride, pad), _out_size(wd, kw, stride, pad)
         col = im2col(x, kh, kw, stride, pad)

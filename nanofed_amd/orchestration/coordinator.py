@@ -30,7 +30,7 @@ import math
 from dataclasses import dataclass
 from datetime import datetime
 from pathlib import Path
-from typing import TYPE_CHECKING, Any, AsyncGenerator, Callable, Sequence
+from typing import TYPE_CHECKING, Any, AsyncGenerator, Callable
 
 import torch
 

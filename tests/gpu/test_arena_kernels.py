@@ -1,6 +1,5 @@
 """HIP arena kernels against fp32 PyTorch references of the same arithmetic."""
 
-import math
 
 import pytest
 import torch

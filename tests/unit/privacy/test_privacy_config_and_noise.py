@@ -1,7 +1,6 @@
 """PrivacyConfig validation and the host noise generators
 (behaviour of nanofed/privacy/config.py and nanofed/privacy/noise/generators.py)."""
 
-import math
 
 import pytest
 import torch

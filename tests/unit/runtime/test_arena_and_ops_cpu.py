@@ -1,7 +1,6 @@
 """Flat arenas and the CPU implementations of the arena ops (the numerical
 oracles of the HIP kernels)."""
 
-import math
 
 import pytest
 import torch

@@ -2,7 +2,6 @@
 (nanofed/server/validation.py, fault_tolerance.py, model_manager/manager.py)."""
 
 import json
-from pathlib import Path
 
 import pytest
 import torch

@@ -4,7 +4,6 @@ import json
 import sys
 
 import torch
-import torch.nn as nn
 
 from nanofed_amd.ops import conv_ops
 
