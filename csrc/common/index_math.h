@@ -79,4 +79,67 @@ NF_IX int conv_patch_index(int W, int logW, int RI, int logRI, int m) {
     return (band * (RI + 2) + r) * (W + 2) + xx;
 }
 
+// Forward / data-gradient kernel: the patch image is padded per row and per band so that
+// the 16 lanes of a ds_read_b128 group - which, for images narrower than 32 pixels, sit in
+// several image rows (and bands) - fall on 16 different 16-byte slots of the 256-byte bank
+// row.  Pixel (band, pr, pc) of the patch starts at band * bp + pr * rp + pc * pitch bytes;
+// rp >= (W + 2) * pitch, bp >= (RI + 2) * rp, all multiples of 16.
+// patch pixel pp (numbered band, row, column) -> byte offset
+NF_IX int conv_patch_byte(int W, int RI, int pp, int pitch, int rp, int bp) {
+    const int PW = W + 2, PR = RI + 2;
+    const int band = pp / (PR * PW);
+    const int rem = pp - band * PR * PW;
+    const int pr = rem / PW, pc = rem - pr * PW;
+    return band * bp + pr * rp + pc * pitch;
+}
+// output pixel m of a tile -> byte offset of its patch pixel without tap shift (tap
+// (ky, kx) adds ky * rp + kx * pitch)
+NF_IX int conv_patch_frag_byte(int W, int logW, int RI, int logRI, int m, int pitch, int rp,
+                               int bp) {
+    const int band = m >> (logRI + logW);
+    const int r = (m >> logW) & (RI - 1);
+    const int xx = m & (W - 1);
+    return band * bp + r * rp + xx * pitch;
+}
+// LDS cycles of the fragment reads of a tile of tp pixels (32 pixels per read, 16-byte
+// pieces): per lane group the largest number of different addresses on one slot, summed
+// over the two groups of each 32-pixel block.  2 per block = conflict-free.
+NF_IX int conv_patch_read_cycles(int W, int logW, int RI, int logRI, int tp, int pitch, int rp,
+                                 int bp) {
+    // lanes of the two ds_read_b128 groups of a 32-lane half
+    const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                               {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int cycles = 0;
+    for (int m0 = 0; m0 < tp; m0 += 32)
+        for (int gi = 0; gi < 2; ++gi) {
+            // the 16 lanes read 16 different pixels: a slot costs one cycle per lane on it
+            int on_slot[16] = {0}, worst = 1;
+            for (int i = 0; i < 16; ++i) {
+                const int a = conv_patch_frag_byte(W, logW, RI, logRI, m0 + groups[gi][i], pitch,
+                                                   rp, bp);
+                const int n = ++on_slot[(a >> 4) & 15];
+                if (n > worst) worst = n;
+            }
+            cycles += worst;
+        }
+    return cycles;
+}
+// Smallest padding (in 16-byte steps, fewer than 16 per row and per band) with the fewest
+// read cycles.
+NF_IX void conv_patch_pitches(int W, int logW, int RI, int logRI, int NI, int tp, int pitch,
+                              int* rp, int* bp) {
+    int best_cycles = 1 << 30, best_bytes = 1 << 30;
+    for (int e = 0; e < 16; ++e)
+        for (int be = 0; be < (NI > 1 ? 16 : 1); ++be) {
+            const int r = (W + 2) * pitch + 16 * e, b = (RI + 2) * r + 16 * be;
+            const int c = conv_patch_read_cycles(W, logW, RI, logRI, tp, pitch, r, b);
+            if (c < best_cycles || (c == best_cycles && NI * b < best_bytes)) {
+                best_cycles = c;
+                best_bytes = NI * b;
+                *rp = r;
+                *bp = b;
+            }
+        }
+}
+
 }  // namespace nfix

@@ -13,7 +13,10 @@
 // reduction runs over chunks of CH (32 or 64) input channels: per chunk the patch
 // and the [64 oc][9 taps][CH ic] weight slice are staged (pitch 2 CH + 16 bytes:
 // 16-byte row-major fragment reads), which makes 9 CH / 16 MFMA k-steps; the next
-// chunk is fetched into registers meanwhile.  Waves are arranged PXW x KSW: PXW
+// chunk is fetched into registers meanwhile.  In images narrower than 32 pixels the 32
+// pixels of a fragment read lie in several patch rows, so the rows (and bands) of the
+// patch are padded by a few 16-byte steps, chosen on the host so that the lanes of every
+// ds_read_b128 group hit different bank groups (nfix::conv_patch_pitches).  Waves are arranged PXW x KSW: PXW
 // pixel groups of 64 pixels, KSW waves sharing the k-steps of one pixel group; the
 // partial accumulators of a pixel group are summed through LDS at the end.  Deep
 // layers (few pixels, many channels) use 1 x 4 with chunks of 64 so that a layer
@@ -36,6 +39,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nf_device.h"
 
@@ -47,6 +51,7 @@ constexpr int kBRows = 64 * 9;            // weight rows of an output-channel ti
 constexpr int kMaxAPieces = 5;            // 16-byte patch pieces per thread and chunk
 constexpr int kRedBytes = 4 * 4 * 16 * 64 * 4;  // accumulators of four waves
 constexpr int kColsumBytes = 4 * 2 * 2 * 32 * 4;  // column-sum staging behind them
+constexpr int kFwdLdsCap = 124 * 1024;    // dynamic LDS the forward kernels may ask for
 
 // forward staging for chunks of CH input channels
 template <int CH>
@@ -71,6 +76,7 @@ struct ConvGeo {
     int Cin, Cout;
     int tpg;               // pixel tiles per group (of the launch's tile size)
     long wgs;              // weight elements between consecutive groups
+    int rp, bp;            // forward kernel: bytes between patch rows / bands in LDS (padded)
 };
 
 // Patch pixel pp of the tile whose first image row (index over b * H + y) is row0:
@@ -83,6 +89,10 @@ __device__ __forceinline__ int patch_source(const ConvGeo& g, int row0, int pp) 
 // Patch index (without tap shift) of pixel m of a tile.
 __device__ __forceinline__ int patch_index(const ConvGeo& g, int m) {
     return nfix::conv_patch_index(g.W, g.logW, g.RI, g.logRI, m);
+}
+// The same as a byte offset into the forward kernel's padded patch image.
+__device__ __forceinline__ int patch_frag_byte(const ConvGeo& g, int m, int pitch) {
+    return nfix::conv_patch_frag_byte(g.W, g.logW, g.RI, g.logRI, m, pitch, g.rp, g.bp);
 }
 
 // kDgrad: the launch computes a data gradient.  x is then dY, y is dX, g.Cin / g.Cout are
@@ -106,7 +116,6 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pw = wave % PXW, kw = wave / PXW;
     const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
-    const int PW = g.W + 2;
     const int row0 = (tile * TP) >> g.logW;
     w += (tile / g.tpg) * g.wgs;  // this group's weights
 
@@ -118,7 +127,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
         if (pp < g.np) {
             const int src = patch_source(g, row0, pp);
             a_src[i] = src < 0 ? -1 : src + p * 8;
-            a_dst[i] = pp * kPitch + p * 16;
+            a_dst[i] = nfix::conv_patch_byte(g.W, g.RI, pp, kPitch, g.rp, g.bp) + p * 16;
         } else {
             a_src[i] = -1;
             a_dst[i] = -1;
@@ -128,7 +137,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     int a_row[2], b_row[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
-        a_row[mb] = patch_index(g, pw * 64 + mb * 32 + (lane & 31)) * kPitch + (lane >> 5) * 16;
+        a_row[mb] = patch_frag_byte(g, pw * 64 + mb * 32 + (lane & 31), kPitch) + (lane >> 5) * 16;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
         b_row[nb] = (nb * 32 + (lane & 31)) * 9 * kPitch + (lane >> 5) * 16;
@@ -205,7 +214,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
         for (int s = s_lo; s < s_hi; ++s) {
             const int tap = s / (CH / 16), sub = s - tap * (CH / 16);
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int aoff = (ky * PW + kx) * kPitch + sub * 32;
+            const int aoff = ky * g.rp + kx * kPitch + sub * 32;
             const int boff = tap * kPitch + sub * 32;
             const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(s_a + a_row[0] + aoff);
             const bf16x8 A1 = *reinterpret_cast<const bf16x8*>(s_a + a_row[1] + aoff);
@@ -499,6 +508,7 @@ bool make_geo(int B, int H, int W, int Cin, int Cout, int tp, int max_patch, Con
     g->Cin = Cin; g->Cout = Cout;
     g->tpg = static_cast<int>(M / tp);
     g->wgs = 0;
+    g->rp = g->bp = 0;  // set by fwd_geo for the forward kernel
     return g->np <= max_patch;
 }
 
@@ -512,7 +522,22 @@ int fwd_tile_pixels(int B, int H, int W, int Cout) {
 bool fwd_geo(int B, int H, int W, int Cin, int Cout, ConvGeo* g) {
     const int tp = fwd_tile_pixels(B, H, W, Cout);
     const int max_patch = tp == 128 ? FwdStage<32>::kMaxPatch : FwdStage<64>::kMaxPatch;
-    return make_geo(B, H, W, Cin, Cout, tp, max_patch, g);
+    if (!make_geo(B, H, W, Cin, Cout, tp, max_patch, g)) return false;
+    const int pitch = tp == 128 ? FwdStage<32>::kPitch : FwdStage<64>::kPitch;
+    nfix::conv_patch_pitches(g->W, g->logW, g->RI, g->logRI, g->NI, tp, pitch, &g->rp, &g->bp);
+    // the larger of the two weight regions (forward, data gradient) beside the patch
+    const int wbytes = tp == 128 ? (FwdStage<32>::kTBBytes > FwdStage<32>::kBBytes ? FwdStage<32>::kTBBytes : FwdStage<32>::kBBytes)
+                                 : (FwdStage<64>::kTBBytes > FwdStage<64>::kBBytes ? FwdStage<64>::kTBBytes : FwdStage<64>::kBBytes);
+    // NANOFED_CONV_PATCH_PAD=0 keeps the plain rows (for measurements)
+    static const bool pad = [] {
+        const char* e = getenv("NANOFED_CONV_PATCH_PAD");
+        return e == nullptr || e[0] != '0';
+    }();
+    if (!pad || wbytes + g->NI * g->bp > kFwdLdsCap) {  // no (room for the) padding: plain rows
+        g->rp = (W + 2) * pitch;
+        g->bp = (g->RI + 2) * g->rp;
+    }
+    return wbytes + g->NI * g->bp <= kFwdLdsCap;
 }
 
 int g_wgrad_min_wgs = 192;
@@ -550,21 +575,21 @@ int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int 
     const bf16* xp = static_cast<const bf16*>(x);
     const bf16* wp = static_cast<const bf16*>(w);
     bf16* yp = static_cast<bf16*>(y);
-    constexpr int kLdsCap = 124 * 1024;
+    constexpr int kLdsCap = kFwdLdsCap;
     static const int lds_ok =
         set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32, kDgrad>), kLdsCap) |
         set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64, kDgrad>), kLdsCap);
     if (lds_ok != 0) return -20;
     if (tp == 128) {
         using St = FwdStage<32>;
-        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.np * St::kPitch;
+        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.NI * g.bp;
         if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
         if (lds > kLdsCap) return -20;
         hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32, kDgrad>), grid, dim3(256), lds, s, xp, wp,
                            yp, colsum, g);
     } else {
         using St = FwdStage<64>;
-        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.np * St::kPitch;
+        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.NI * g.bp;
         if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
         if (lds > kLdsCap) return -20;
         hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64, kDgrad>), grid, dim3(256), lds, s, xp, wp,

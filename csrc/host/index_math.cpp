@@ -16,5 +16,27 @@ int nf_ix_conv_patch_source(int H, int W, int logH, int RI, int Cin, int row0, i
 int nf_ix_conv_patch_index(int W, int logW, int RI, int logRI, int m) {
     return nfix::conv_patch_index(W, logW, RI, logRI, m);
 }
+int nf_ix_conv_patch_byte(int W, int RI, int pp, int pitch, int rp, int bp) {
+    return nfix::conv_patch_byte(W, RI, pp, pitch, rp, bp);
+}
+int nf_ix_conv_patch_frag_byte(int W, int logW, int RI, int logRI, int m, int pitch, int rp,
+                               int bp) {
+    return nfix::conv_patch_frag_byte(W, logW, RI, logRI, m, pitch, rp, bp);
+}
+int nf_ix_conv_patch_read_cycles(int W, int logW, int RI, int logRI, int tp, int pitch, int rp,
+                                 int bp) {
+    return nfix::conv_patch_read_cycles(W, logW, RI, logRI, tp, pitch, rp, bp);
+}
+// rp and bp packed as rp | bp << 16 would overflow for large bands: two calls instead
+int nf_ix_conv_patch_row_pitch(int W, int logW, int RI, int logRI, int NI, int tp, int pitch) {
+    int rp = 0, bp = 0;
+    nfix::conv_patch_pitches(W, logW, RI, logRI, NI, tp, pitch, &rp, &bp);
+    return rp;
+}
+int nf_ix_conv_patch_band_pitch(int W, int logW, int RI, int logRI, int NI, int tp, int pitch) {
+    int rp = 0, bp = 0;
+    nfix::conv_patch_pitches(W, logW, RI, logRI, NI, tp, pitch, &rp, &bp);
+    return bp;
+}
 
 }  // extern "C"

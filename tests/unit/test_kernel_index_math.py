@@ -16,7 +16,9 @@ def ix():
     native_build.build_host()
     lib = ctypes.CDLL(str(native_build.HOST_LIB))
     for name in ("gemm_kc_off", "gemm_km_off", "gemm_tile_index", "mnist_fwd_swz", "mnist_dg_swz",
-                 "mfma32_acc_row", "conv_patch_source", "conv_patch_index"):
+                 "mfma32_acc_row", "conv_patch_source", "conv_patch_index", "conv_patch_byte",
+                 "conv_patch_frag_byte", "conv_patch_read_cycles", "conv_patch_row_pitch",
+                 "conv_patch_band_pitch"):
         getattr(lib, f"nf_ix_{name}").restype = ctypes.c_int
     return lib
 
@@ -110,3 +112,37 @@ def test_conv_patch_maps_stay_inside_the_tensor_and_the_patch(ix, H, W, RI, NI):
             centre = sources[p + (W + 2) + 1]
             grow = row0 + m // W
             assert centre == ((grow // H * H + grow % H) * W + m % W) * Cin
+
+
+@pytest.mark.parametrize("pitch,tp", [(80, 128), (144, 64)])
+@pytest.mark.parametrize("H,W", [(32, 32), (16, 16), (8, 8), (4, 4)])
+def test_padded_conv_patch_is_disjoint_and_its_fragment_reads_conflict_free(ix, H, W, pitch, tp):
+    rows = tp // W
+    RI = min(rows, H)
+    NI = rows // RI
+    logW, logRI = W.bit_length() - 1, RI.bit_length() - 1
+    args = (W, logW, RI, logRI, NI, tp, pitch)
+    rp, bp = ix.nf_ix_conv_patch_row_pitch(*args), ix.nf_ix_conv_patch_band_pitch(*args)
+    assert rp % 16 == 0 and bp % 16 == 0
+    assert (W + 2) * pitch <= rp < (W + 2) * pitch + 256 and (RI + 2) * rp <= bp < (RI + 2) * rp + 256
+    patch = NI * (RI + 2) * (W + 2)
+    # every patch pixel owns pitch - 16 bytes of its own inside the image
+    starts = sorted(ix.nf_ix_conv_patch_byte(W, RI, pp, pitch, rp, bp) for pp in range(patch))
+    assert starts[0] == 0 and starts[-1] + pitch - 16 <= NI * bp
+    assert all(b - a >= pitch for a, b in zip(starts, starts[1:]))
+    assert all(s % 16 == 0 for s in starts)
+    # an output pixel's taps are the staged pixels around it
+    staged = {ix.nf_ix_conv_patch_byte(W, RI, pp, pitch, rp, bp): pp for pp in range(patch)}
+    for m in range(tp):
+        base = ix.nf_ix_conv_patch_frag_byte(W, logW, RI, logRI, m, pitch, rp, bp)
+        p = ix.nf_ix_conv_patch_index(W, logW, RI, logRI, m)
+        for ky in range(3):
+            for kx in range(3):
+                assert staged[base + ky * rp + kx * pitch] == p + ky * (W + 2) + kx
+    # one LDS cycle per lane group: 2 per block of 32 pixels; the plain layout needs more
+    # for images narrower than 32 pixels
+    assert ix.nf_ix_conv_patch_read_cycles(W, logW, RI, logRI, tp, pitch, rp, bp) == 2 * (tp // 32)
+    plain_rp = (W + 2) * pitch
+    plain = ix.nf_ix_conv_patch_read_cycles(W, logW, RI, logRI, tp, pitch, plain_rp,
+                                            (RI + 2) * plain_rp)
+    assert plain == 2 * (tp // 32) if W == 32 else plain > 2 * (tp // 32)
