@@ -70,6 +70,8 @@ def main() -> int:
                     choices=["synthetic_mnist_hard", "synthetic_mnist", "mnist"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="run on CPU/gloo (plumbing check)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not queue the next round before the host has finished the current one")
     ap.add_argument("--no-persist", action="store_true",
                     help="leave the per-round model version / metrics files out of the timed rounds")
     ap.add_argument("--eval-samples", type=int, default=10000)
@@ -108,6 +110,7 @@ def main() -> int:
         backend=args.backend,
         graph_capture=not args.no_graph,
         eval_samples=args.eval_samples,
+        prefetch_rounds=not args.no_prefetch,
     )
     scratch = None
     if not args.no_persist and comm.is_root:
@@ -122,7 +125,9 @@ def main() -> int:
         comm.barrier()
         sync()
         t0 = time.perf_counter()
-        reps = [engine.run_round(flush=False) for _ in range(rounds)]
+        # the engine queues round i + 1 on the device while the host finishes round i
+        # (as FederatedEngine.run does); the last timed round queues nothing
+        reps = [engine.run_round(flush=False, prefetch_next=i + 1 < rounds) for i in range(rounds)]
         engine.flush()  # the last rounds' files are on disk before the clock stops
         sync()
         comm.barrier()

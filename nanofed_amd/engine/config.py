@@ -114,6 +114,9 @@ class EngineConfig:
     # capture the round's tail (screening, weights, weighted sum, select) in a
     # hipGraph (single-rank GPU runs)
     tail_graph: bool = True
+    # in run(): queue the next round's broadcast and local training on the device before
+    # the host waits for the current round's outcome (no device idle time between rounds)
+    prefetch_rounds: bool = True
     # observability: HIP-event timing of the round's phases (extra key
     # "phases_ms" in the round metrics JSON)
     phase_timing: bool = True

@@ -304,6 +304,16 @@ class FederatedEngine:
         self._control = torch.zeros(W, **f32)
         # everything the host reads at the end of a round, in one buffer
         self._host_pack = torch.zeros(K * METRIC_COLUMNS + 4 + W, **f32)
+        # the next round's broadcast and local training, queued behind this round's tail
+        # before the host looks at this round's outcome: (round id, metrics tensor)
+        self._prelaunched: tuple[int, torch.Tensor] | None = None
+        self._host_pack_pinned: torch.Tensor | None = None
+        self._pack_event = None
+        self._select_done = None
+        if self.device.type == "cuda":
+            self._host_pack_pinned = torch.empty_like(self._host_pack, device="cpu").pin_memory()
+            self._pack_event = torch.cuda.Event()
+            self._select_done = torch.cuda.Event()
         self._need_delta = cfg.max_update_norm > 0 or cfg.zscore_threshold > 0
         self._tail_graph: torch.cuda.CUDAGraph | None = None
         self._tail_rounds = 0
@@ -343,6 +353,7 @@ class FederatedEngine:
         if self.base_dir is not None and self.comm.is_root:
             self._setup_persistence()
         self._in_run = False
+        self._more_rounds = False  # inside run(): another round follows the current one
         self._watchdog: _Watchdog | None = None
         if cfg.enforce_round_timeout and cfg.round_timeout_s > 0:
             self._watchdog = _Watchdog(
@@ -462,19 +473,30 @@ class FederatedEngine:
         self._shares = torch.tensor(self._shares_host, dtype=torch.float32).to(self.device)
 
     # -- the round --------------------------------------------------------
-    def run_round(self, flush: bool | None = None) -> RoundReport:
+    def run_round(self, flush: bool | None = None, prefetch_next: bool | None = None) -> RoundReport:
         """One federated round.  ``flush=False`` leaves the round's persistence
         with the writer thread (``run`` and the benchmark flush once at the end);
-        the default flushes unless the call comes from ``run``."""
+        the default flushes unless the call comes from ``run``.
+
+        ``prefetch_next=True`` says that the caller will run another round right after
+        this one: its broadcast and local training are then queued on the device behind
+        this round's tail *before* the host waits for this round's outcome, so the device
+        does not idle while the host builds the report and hands the round to the writer
+        (``run`` does this for every round but the last).  If this round does not complete
+        (quorum lost), the queued work is for a round that will not come; the next call
+        notices the round number and trains again from the unchanged model - the trainers
+        keep no state across rounds, so nothing has to be undone."""
         if flush is None:
             flush = not self._in_run
+        if prefetch_next is None:
+            prefetch_next = self._in_run and self._more_rounds
         r = self.round_id
         t0 = time.perf_counter()
         start = get_current_time()
         if self._watchdog is not None:
             self._watchdog.arm(r)
         try:
-            report = self._round(r, t0, start)
+            report = self._round(r, t0, start, prefetch_next and self._may_prefetch())
         finally:
             if self._watchdog is not None:
                 self._watchdog.disarm()
@@ -482,7 +504,20 @@ class FederatedEngine:
             self.flush()
         return report
 
-    def _round(self, r: int, t0: float, start) -> RoundReport:
+    def _may_prefetch(self) -> bool:
+        """Queueing the next round early is kept to runs whose rounds the host does not
+        touch between training and aggregation and that do not roll back: no fault plan,
+        no signatures, no checkpoint-and-recover (its recovery point of last resort is the
+        model at the start of the *failed* round)."""
+        cfg = self.cfg
+        f = self.faults
+        planned = any((f.drop, f.poison, f.scale, f.delay, f.fail, f.stall, f.tamper))
+        return (
+            cfg.prefetch_rounds and not planned and not self._signers
+            and not cfg.checkpoint_rounds and cfg.secure_agg != "pairwise"
+        )
+
+    def _round(self, r: int, t0: float, start, prefetch_next: bool = False) -> RoundReport:
         cfg, comm = self.cfg, self.comm
         timer = self._timer
         multi = comm.world_size > 1
@@ -493,17 +528,25 @@ class FederatedEngine:
                 self._persister.raise_pending()
             except Exception as exc:  # noqa: BLE001
                 failure = exc
+        # this round's broadcast and training may already be in the queue (run_round)
+        queued, self._prelaunched = self._prelaunched, None
+        if queued is not None and (queued[0] != r or failure is not None):
+            queued = None  # for a round that did not come: train again from the model as it is
         # 1. broadcast
-        with timer.phase("broadcast"):
-            self.pool.broadcast_from(self.global_arena.data)
-            if self._round_start is not None:
-                self._round_start.copy_(self.global_arena.data)
+        if queued is None:
+            with timer.phase("broadcast"):
+                self.pool.broadcast_from(self.global_arena.data)
+                if self._round_start is not None:
+                    self._round_start.copy_(self.global_arena.data)
         # 2. local training
         local = None
         try:
             if failure is None:
-                with timer.phase("local_train"):
-                    local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
+                if queued is not None:
+                    local = queued[1]
+                else:
+                    with timer.phase("local_train"):
+                        local = self.trainer.train_round(r)  # [G, METRIC_COLUMNS] on device
                 signatures = self._sign_rows(r) if self._signers else None
                 self._inject_faults(r, local)
                 if signatures is not None:
@@ -514,8 +557,32 @@ class FederatedEngine:
         if failure is not None and not multi:
             raise failure
         self._tail(local, failed=failure is not None, eager=failure is not None or self._faulty(r))
+        if self._select_done is not None:
+            self._select_done.record()  # what a snapshot of the new model waits for
         # 8. the only host synchronisation of the round
-        host = self._host_pack.cpu()
+        spans = None
+        if prefetch_next and failure is None:
+            # copy the outcome out without blocking, queue the next round behind it, and
+            # only then wait for the copy
+            if self._host_pack_pinned is not None:
+                self._host_pack_pinned.copy_(self._host_pack, non_blocking=True)
+                self._pack_event.record()
+                host = self._host_pack_pinned
+            else:
+                host = self._host_pack.clone()
+            spans = timer.detach()  # this round's phases; the queued round's go to the next
+            try:
+                with timer.phase("broadcast"):
+                    self.pool.broadcast_from(self.global_arena.data)
+                with timer.phase("local_train"):
+                    self._prelaunched = (r + 1, self.trainer.train_round(r + 1))
+            except Exception:  # noqa: BLE001 - the round itself will run into it again
+                self._prelaunched = None
+                timer.detach()
+            if self._host_pack_pinned is not None:
+                self._pack_event.synchronize()
+        else:
+            host = self._host_pack.cpu()
         K, W = self._K, comm.world_size
         rec = host[: K * METRIC_COLUMNS].view(K, METRIC_COLUMNS).numpy()
         flags = host[K * METRIC_COLUMNS : K * METRIC_COLUMNS + 4]
@@ -528,7 +595,10 @@ class FederatedEngine:
                 failure, ranks,
             ) from failure
         succeeded = bool(flags[0] > 0)
-        phases = timer.collect() if cfg.phase_timing else {}
+        if spans is not None:
+            phases = timer.summarize(spans) if cfg.phase_timing else {}
+        else:
+            phases = timer.collect() if cfg.phase_timing else {}
 
         report = self._report(r, rec, succeeded, start, time.perf_counter() - t0)
         report.phases_ms = phases
@@ -773,7 +843,9 @@ class FederatedEngine:
             buf.copy_(self.global_arena.data)
             return buf, None
         main = torch.cuda.current_stream(self.device)
-        self._copy_stream.wait_stream(main)
+        # after the round's select; not after whatever else is queued by now (the next
+        # round's training, which only reads the arena)
+        self._copy_stream.wait_event(self._select_done)
         with torch.cuda.stream(self._copy_stream):
             buf.copy_(self.global_arena.data, non_blocking=True)
             self._snap_events[slot].record()
@@ -918,6 +990,7 @@ class FederatedEngine:
         try:
             while len(out) < target:
                 try:
+                    self._more_rounds = len(out) + 1 < target
                     out.append(self.run_round())
                 except Exception as failure:  # noqa: BLE001 - the strategy decides
                     cause = failure
@@ -943,6 +1016,7 @@ class FederatedEngine:
         if not self.cfg.checkpoint_rounds or self.recoveries >= self.cfg.max_recoveries:
             return False
         self.recoveries += 1
+        self._prelaunched = None
         self._timer.collect()
         self._tail_graph = None  # recaptured on a quiet round
         self._tail_rounds = 0
@@ -983,6 +1057,7 @@ class FederatedEngine:
         restarts at round 0, nanofed/server/model_manager/manager.py:144-188).
         Returns the round the engine will run next."""
         self._resumed = True
+        self._prelaunched = None
         state = torch.zeros(1, dtype=torch.float32, device=self.device)
         if self.comm.is_root and self._model_manager is not None:
             versions = self._model_manager.list_versions()

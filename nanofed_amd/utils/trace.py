@@ -96,15 +96,23 @@ class PhaseTimer:
                 finally:
                     self._spans.append((name, t0, time.perf_counter()))
 
+    def detach(self) -> list[tuple[str, object, object]]:
+        """Hand over the spans recorded so far (for ``summarize``) and start afresh: what is
+        recorded from here on belongs to the next collection."""
+        spans, self._spans = self._spans, []
+        return spans
+
     def collect(self) -> dict[str, float]:
         """Milliseconds per phase (summed over repeated names); clears the timer."""
+        return self.summarize(self.detach())
+
+    def summarize(self, spans: list[tuple[str, object, object]]) -> dict[str, float]:
         out: dict[str, float] = {}
-        for name, begin, end in self._spans:
+        for name, begin, end in spans:
             if self._gpu:
                 end.synchronize()  # type: ignore[union-attr]
                 ms = float(begin.elapsed_time(end))  # type: ignore[union-attr]
             else:
                 ms = (end - begin) * 1000.0  # type: ignore[operator]
             out[name] = out.get(name, 0.0) + ms
-        self._spans.clear()
         return out

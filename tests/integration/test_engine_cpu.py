@@ -151,3 +151,64 @@ def test_two_process_gloo_run_matches_single_process(tmp_path, algo):
     assert dist["n"] == 4
     torch.testing.assert_close(dist["flat"], single.global_arena.data, rtol=1e-5, atol=1e-6)
     assert dist["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-4)
+
+
+# -- the next round queued before the host has finished the current one -------------------
+_PREFETCH_CFG = dict(model="mnist_mlp", num_clients=4, samples_per_client=[96, 64, 64, 32],
+                     batch_size=32, local_epochs=2, eval_samples=64, dtype="fp32",
+                     backend="torch", model_kwargs={"hidden": 16}, learning_rate=0.1)
+
+
+def _run_prefetch(rounds=4, **kw):
+    eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG, **kw), comm=Communicator())
+    reports = eng.run(rounds)
+    return eng, reports
+
+
+def test_queueing_the_next_round_early_changes_nothing_but_the_order_of_host_work():
+    early, ra = _run_prefetch(prefetch_rounds=True)
+    plain, rb = _run_prefetch(prefetch_rounds=False)
+    assert torch.equal(early.global_arena.data, plain.global_arena.data)
+    assert [r.round_id for r in ra] == [0, 1, 2, 3] and early.round_id == 4
+    assert [r.agg_metrics for r in ra] == [r.agg_metrics for r in rb]
+    # every round reports its own phases, the queued ones included
+    for rep in ra:
+        assert {"broadcast", "local_train", "reduce"} <= set(rep.phases_ms)
+    assert early._prelaunched is None  # the last round of run() queues nothing
+
+
+def test_a_round_queued_for_nothing_is_trained_again_from_the_unchanged_model():
+    # every client is screened out, so every round loses its quorum and the round counter
+    # never advances: the round queued early (r + 1) never comes
+    early, ra = _run_prefetch(rounds=3, prefetch_rounds=True, max_update_norm=1e-9)
+    plain, rb = _run_prefetch(rounds=3, prefetch_rounds=False, max_update_norm=1e-9)
+    assert [r.status for r in ra] == ["FAILED"] * 3 and early.round_id == 0
+    assert torch.equal(early.global_arena.data, plain.global_arena.data)
+    assert [r.client_metrics for r in ra] == [r.client_metrics for r in rb]
+
+
+def test_single_rounds_queue_nothing_unless_asked_and_a_resume_drops_what_was_queued(tmp_path):
+    eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG), comm=Communicator(), base_dir=tmp_path)
+    eng.run_round()
+    assert eng._prelaunched is None
+    eng.run_round(prefetch_next=True)
+    assert eng._prelaunched is not None and eng._prelaunched[0] == 2
+    assert eng.resume() == 2 and eng._prelaunched is None
+    after = eng.run_round()
+    ref = FederatedEngine(EngineConfig(**_PREFETCH_CFG), comm=Communicator())
+    ref.run(3)
+    assert after.round_id == 2 and torch.equal(eng.global_arena.data, ref.global_arena.data)
+    eng.close()
+
+
+def test_runs_that_roll_back_or_inject_faults_keep_the_plain_order():
+    from nanofed_amd.engine import FaultPlan
+
+    eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG, checkpoint_rounds=True), comm=Communicator())
+    assert not eng._may_prefetch()
+    eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG), comm=Communicator(),
+                          faults=FaultPlan(drop={1: {0}}))
+    assert not eng._may_prefetch()
+    eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG, sign_updates=True), comm=Communicator())
+    assert not eng._may_prefetch()
+    assert FederatedEngine(EngineConfig(**_PREFETCH_CFG), comm=Communicator())._may_prefetch()
