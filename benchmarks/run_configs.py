@@ -62,7 +62,8 @@ def run_engine(name: str, args) -> dict:
     comm.barrier()
     engine.synchronize()
     t0 = time.perf_counter()
-    reports = [engine.run_round() for _ in range(args.rounds)]
+    # as FederatedEngine.run does: round i + 1 is queued while the host finishes round i
+    reports = [engine.run_round(prefetch_next=i + 1 < args.rounds) for i in range(args.rounds)]
     engine.synchronize()
     comm.barrier()
     dt = comm.max_over_ranks(time.perf_counter() - t0)
