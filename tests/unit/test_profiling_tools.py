@@ -61,3 +61,40 @@ def test_steady_state_table_uses_only_the_last_steps(tmp_path):
     assert by_name["conv3x3_fwd_kernel"]["calls_per_step"] == 1.0
     assert by_name["conv3x3_fwd_kernel"]["us_per_call"] == 10.0
     assert abs(table["busy_us_per_step"] - 17.0) < 1e-6
+
+
+def _trace_db(path, dispatches):
+    """A result database with the two tables the trace tools read."""
+    import sqlite3
+
+    con = sqlite3.connect(path)
+    con.execute("create table rocpd_info_kernel_symbol (id integer, kernel_name text)")
+    con.execute("create table rocpd_kernel_dispatch (queue_id integer, start integer, end integer, "
+                "kernel_id integer)")
+    names = sorted({d[3] for d in dispatches})
+    con.executemany("insert into rocpd_info_kernel_symbol values (?, ?)", list(enumerate(names)))
+    con.executemany("insert into rocpd_kernel_dispatch values (?, ?, ?, ?)",
+                    [(q, s, e, names.index(n)) for q, s, e, n in dispatches])
+    con.commit()
+    con.close()
+
+
+def test_idle_intervals_count_time_no_queue_is_busy(tmp_path):
+    # two queues: queue 1 covers the first gap of queue 0 but not the second
+    ns = 1000
+    dispatches = [
+        (0, 0, 100 * ns, "a_kernel"), (0, 150 * ns, 250 * ns, "b_kernel"),
+        (1, 90 * ns, 160 * ns, "c_kernel"),
+        (0, 300 * ns, 400 * ns, "a_kernel"),
+    ]
+    db = tmp_path / "t_results.db"
+    _trace_db(db, dispatches)
+    res = subprocess.run(
+        [sys.executable, "idle_intervals.py", str(db), "--min-us", "10"],
+        capture_output=True, text=True, check=True, cwd=ROOT / "tools",
+    )
+    lines = res.stdout.splitlines()
+    assert lines[0] == "span_us,400.0" and lines[1] == "idle_us,50.0"
+    assert lines[2] == "busy_share,0.8750"
+    assert "b_kernel,a_kernel,1,50.0,50.0,50.0" in lines
+    assert not any(line.startswith("a_kernel,b_kernel") for line in lines)
