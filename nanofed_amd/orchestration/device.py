@@ -84,6 +84,7 @@ class DeviceCoordinator:
         self._round_metrics: list[RoundMetrics] = []
         self._status = RoundStatus.INITIALIZED
         self._round_lock = asyncio.Lock()
+        self._more_rounds = False  # set by start_training: another round follows
 
         base = Path(config.base_dir)
         self._data_dir = base / "data"
@@ -180,7 +181,9 @@ class DeviceCoordinator:
                 try:
                     # synchronous on purpose: HIP's current device and torch's
                     # current stream belong to this thread
-                    report = self._engine.run_round()
+                    # inside start_training the engine queues the next round on the
+                    # device while this one's report is being built and handed out
+                    report = self._engine.run_round(prefetch_next=self._more_rounds)
                 except Exception as exc:
                     self._status = RoundStatus.FAILED
                     self._logger.error(f"Error in round {self.current_round}: {exc}")
@@ -233,6 +236,7 @@ class DeviceCoordinator:
             try:
                 done = 0
                 while done < self._config.num_rounds:
+                    self._more_rounds = done + 1 < self._config.num_rounds
                     try:
                         metrics = await self.train_round()
                     except TimeoutError:
@@ -252,6 +256,7 @@ class DeviceCoordinator:
                 self._logger.error(f"Training failed: {exc}")
                 raise
             finally:
+                self._more_rounds = False
                 self._engine.flush()
                 self._logger.info("Training completed")
 
