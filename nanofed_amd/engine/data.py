@@ -142,9 +142,10 @@ class DeviceShards:
         shape = (1, -1, 1, 1)
         self.mean = torch.tensor(data.mean, dtype=torch.float32, device=device).view(shape)
         self.std = torch.tensor(data.std, dtype=torch.float32, device=device).view(shape)
-        self._gen = (
-            torch.Generator(device=device) if device.type == "cuda" else torch.Generator()
-        )
+        # The shuffles are drawn on the host, whatever the device: the same permutations on
+        # every device, and no chain of tiny sort kernels competing with training for a
+        # hardware queue (the host is idle while an epoch's launches run).
+        self._gen = torch.Generator()
 
     def steps_per_epoch(self, k: int) -> int:
         n, b = self.sizes[k], self.batch_size
@@ -153,13 +154,24 @@ class DeviceShards:
     def max_steps(self) -> int:
         return max((self.steps_per_epoch(k) for k in range(len(self.sizes))), default=0)
 
-    def epoch_permutation(self, k: int, round_idx: int, epoch: int) -> torch.Tensor:
-        """Row indices (into ``self.inputs``) of client k's samples, shuffled."""
+    def host_permutation(self, k: int, round_idx: int, epoch: int, pinned: bool = False) -> torch.Tensor:
+        """Row indices (into ``self.inputs``) of client k's samples, shuffled: an int64
+        tensor in host memory (page-locked on request), a function of (seed, client id,
+        round, epoch) only."""
         cid = self.client_ids[k]
         mix = (self.seed * 1000003 + cid * 7919 + round_idx * 104729 + epoch) & 0x7FFFFFFFFFFF
         self._gen.manual_seed(mix)
-        perm = torch.randperm(self.sizes[k], generator=self._gen, device=self.device)
-        return perm + int(self.offsets[k])
+        out = torch.empty(self.sizes[k], dtype=torch.int64, pin_memory=pinned)
+        torch.randperm(self.sizes[k], generator=self._gen, out=out)
+        return out.add_(int(self.offsets[k]))
+
+    def epoch_permutation(self, k: int, round_idx: int, epoch: int) -> torch.Tensor:
+        """The same on the training device.  The copy from page-locked memory does not block
+        the host (the caching host allocator keeps the buffer until the copy has run)."""
+        if self.device.type != "cuda":
+            return self.host_permutation(k, round_idx, epoch)
+        host = self.host_permutation(k, round_idx, epoch, pinned=True)
+        return host.to(self.device, non_blocking=True)
 
     def batch(self, rows: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """Assemble a normalised batch (torch path)."""

@@ -34,7 +34,6 @@ import torch.nn as nn
 from nanofed_amd.core.exceptions import DeviceError
 from nanofed_amd.ops import library
 from nanofed_amd.runtime.arena import ArenaLayout, ArenaPool
-from nanofed_amd.utils.streams import side_stream
 
 from .config import EngineConfig
 from .data import DeviceShards, FederatedData
@@ -396,8 +395,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
             nvalid[k] = ok.sum(dim=1).to(torch.int32)
             per_batch = nvalid[k].view(self.max_steps, m).sum(dim=1)
             ntotal[k] = per_batch.repeat_interleave(m)
-            self._gather_pos.append(torch.where(ok, pos, torch.zeros_like(pos)).reshape(-1).to(self.device))
-            self._gather_ok.append(ok.reshape(-1).to(self.device))
+            self._gather_pos.append(torch.where(ok, pos, torch.zeros_like(pos)).reshape(-1))
+            self._gather_ok.append(ok.reshape(-1))
         self.buf.nvalid.copy_(nvalid)
         self.buf.ntotal.copy_(ntotal)
         # unequal shards: the kernels skip a client's workgroups once it has no batch left
@@ -431,12 +430,8 @@ class MnistCnnNativeTrainer(GroupTrainer):
         self._graphs: list[list[torch.cuda.CUDAGraph]] | None = None
         self._chunks: list[tuple[int, int]] = []
         self._stream_trials: list[tuple[float, list[torch.cuda.Stream]]] = []
-        # staging table and (default-priority) side stream for the epoch shuffles
-        self._idx_stage = torch.empty_like(self.buf.idx)
-        self._idx_stream = side_stream(self.device) if cfg.graph_capture else None
-        self._idx_ready = torch.cuda.Event()
-        self._idx_consumed = torch.cuda.Event()
-        self._idx_consumed.record(torch.cuda.current_stream(self.device))
+        # the next epoch's index table, built on the host while the current epoch runs
+        self._idx_host: torch.Tensor | None = None
         self._idx_key: tuple[int, int] | None = None
         self._eval: NativeBuffers | None = None
         self._eval_data = (data.eval_inputs, data.eval_labels, mean, std)
@@ -464,37 +459,37 @@ class MnistCnnNativeTrainer(GroupTrainer):
         return [size] * (G // size) + ([G % size] if G % size else [])
 
     # -- batches ----------------------------------------------------------
-    def _fill_indices(self, round_idx: int, epoch: int, into: torch.Tensor | None = None) -> None:
-        target = self.buf.idx if into is None else into
-        for k in range(len(self.pool)):
-            perm = self.shards.epoch_permutation(k, round_idx, epoch).to(torch.int32)
+    def _host_indices(self, round_idx: int, epoch: int) -> torch.Tensor:
+        """The epoch's index table [clients, table steps * 64] in page-locked host memory:
+        the clients' shuffles (drawn on the host) gathered into batch order."""
+        G = len(self.pool)
+        table = torch.empty(G, self.buf.idx.shape[1], dtype=torch.int32, pin_memory=True)
+        for k in range(G):
+            perm = self.shards.host_permutation(k, round_idx, epoch)
             # rows beyond the batch or the shard repeat the first sample (zero loss weight)
             row = perm[self._gather_pos[k]]
-            target[k].copy_(torch.where(self._gather_ok[k], row, perm[0]))
+            table[k].copy_(torch.where(self._gather_ok[k], row, perm[0]))
+        return table
 
-    # The shuffles of an epoch are a few dozen tiny launches per client.  They are
-    # issued on a second stream while the previous epoch's graph is running and
-    # land in a staging table; the training stream only pays for one copy.
+    def _fill_indices(self, round_idx: int, epoch: int) -> None:
+        self.buf.idx.copy_(self._host_indices(round_idx, epoch), non_blocking=True)
+
+    # An epoch's shuffles used to be a few dozen tiny sort launches per client on a side
+    # stream; a process has four hardware queues, the side stream shared one with a
+    # training chain, and the training stream waited 0.3-0.4 ms per epoch for them.  The
+    # host, idle while an epoch's launches run, draws them now: the table of the next
+    # epoch is built right after the current epoch has been queued, and the training
+    # stream pays one 240 KB copy.
     def _prefetch_indices(self, round_idx: int, epoch: int) -> None:
-        if self._idx_stream is None:
-            return
-        self._idx_stream.wait_event(self._idx_consumed)
-        with torch.cuda.stream(self._idx_stream):
-            self._fill_indices(round_idx, epoch, into=self._idx_stage)
-            self._idx_ready.record()
+        self._idx_host = self._host_indices(round_idx, epoch)
         self._idx_key = (round_idx, epoch)
 
     def _take_indices(self, round_idx: int, epoch: int) -> None:
-        if self._idx_stream is None:
-            self._fill_indices(round_idx, epoch)
-            return
         if self._idx_key != (round_idx, epoch):
             self._prefetch_indices(round_idx, epoch)
-        main = torch.cuda.current_stream(self.device)
-        main.wait_event(self._idx_ready)
-        self.buf.idx.copy_(self._idx_stage)
-        self._idx_consumed.record(main)
-        self._idx_key = None
+        # the caching host allocator keeps the table until the copy has run
+        self.buf.idx.copy_(self._idx_host, non_blocking=True)
+        self._idx_host, self._idx_key = None, None
 
     def _ensure_graph(self, round_idx: int) -> None:
         """Record one local epoch (every step of every client of a group) in a
