@@ -26,6 +26,7 @@ in examples/mnist/tutorial.ipynb:523 of the reference).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import shutil
@@ -136,6 +137,10 @@ def main() -> int:
 
     for _ in range(args.warmup):
         engine.run_round()
+    # everything built so far (modules, graphs, buffers) lives as long as the process: keep
+    # it out of the cyclic collector's scans, whose full passes take 50-60 ms here
+    gc.collect()
+    gc.freeze()
     elapsed, reports = timed(args.steps)
     final = engine.evaluate()
     dump = engine.global_arena.data.detach().cpu().clone() if args.dump_model else None

@@ -28,6 +28,7 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -395,8 +396,10 @@ class MnistCnnNativeTrainer(GroupTrainer):
             nvalid[k] = ok.sum(dim=1).to(torch.int32)
             per_batch = nvalid[k].view(self.max_steps, m).sum(dim=1)
             ntotal[k] = per_batch.repeat_interleave(m)
-            self._gather_pos.append(torch.where(ok, pos, torch.zeros_like(pos)).reshape(-1))
-            self._gather_ok.append(ok.reshape(-1))
+            # (numpy: the tables are built on the host every epoch, and numpy's gathers do
+            # not go through a thread pool that may have to wake up first)
+            self._gather_pos.append(torch.where(ok, pos, torch.zeros_like(pos)).reshape(-1).numpy())
+            self._gather_ok.append(ok.reshape(-1).numpy())
         self.buf.nvalid.copy_(nvalid)
         self.buf.ntotal.copy_(ntotal)
         # unequal shards: the kernels skip a client's workgroups once it has no batch left
@@ -430,8 +433,13 @@ class MnistCnnNativeTrainer(GroupTrainer):
         self._graphs: list[list[torch.cuda.CUDAGraph]] | None = None
         self._chunks: list[tuple[int, int]] = []
         self._stream_trials: list[tuple[float, list[torch.cuda.Stream]]] = []
-        # the next epoch's index table, built on the host while the current epoch runs
-        self._idx_host: torch.Tensor | None = None
+        # the next epoch's index table, built on the host while the current epoch runs:
+        # a ring of page-locked tables (allocated once: page-locking memory can take tens
+        # of milliseconds), each guarded by the event of the last copy that read it
+        self._idx_ring = [torch.empty_like(self.buf.idx, device="cpu").pin_memory() for _ in range(3)]
+        self._idx_ring_events: list[torch.cuda.Event | None] = [None] * len(self._idx_ring)
+        self._idx_ring_next = 0
+        self._idx_host: int | None = None  # ring slot that holds the table of _idx_key
         self._idx_key: tuple[int, int] | None = None
         self._eval: NativeBuffers | None = None
         self._eval_data = (data.eval_inputs, data.eval_labels, mean, std)
@@ -459,20 +467,31 @@ class MnistCnnNativeTrainer(GroupTrainer):
         return [size] * (G // size) + ([G % size] if G % size else [])
 
     # -- batches ----------------------------------------------------------
-    def _host_indices(self, round_idx: int, epoch: int) -> torch.Tensor:
-        """The epoch's index table [clients, table steps * 64] in page-locked host memory:
-        the clients' shuffles (drawn on the host) gathered into batch order."""
-        G = len(self.pool)
-        table = torch.empty(G, self.buf.idx.shape[1], dtype=torch.int32, pin_memory=True)
-        for k in range(G):
-            perm = self.shards.host_permutation(k, round_idx, epoch)
+    def _host_indices(self, round_idx: int, epoch: int) -> int:
+        """Build the epoch's index table [clients, table steps * 64] - the clients' shuffles
+        (drawn on the host) gathered into batch order - in the next page-locked table of the
+        ring; returns its slot."""
+        slot = self._idx_ring_next
+        self._idx_ring_next = (slot + 1) % len(self._idx_ring)
+        last_copy = self._idx_ring_events[slot]
+        if last_copy is not None:
+            last_copy.synchronize()  # two tables ago: has run long since
+        table = self._idx_ring[slot].numpy()
+        for k in range(len(self.pool)):
+            perm = self.shards.host_permutation(k, round_idx, epoch).numpy()
             # rows beyond the batch or the shard repeat the first sample (zero loss weight)
             row = perm[self._gather_pos[k]]
-            table[k].copy_(torch.where(self._gather_ok[k], row, perm[0]))
-        return table
+            np.copyto(table[k], np.where(self._gather_ok[k], row, perm[0]), casting="unsafe")
+        return slot
+
+    def _copy_indices(self, slot: int) -> None:
+        self.buf.idx.copy_(self._idx_ring[slot], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._idx_ring_events[slot] = done
 
     def _fill_indices(self, round_idx: int, epoch: int) -> None:
-        self.buf.idx.copy_(self._host_indices(round_idx, epoch), non_blocking=True)
+        self._copy_indices(self._host_indices(round_idx, epoch))
 
     # An epoch's shuffles used to be a few dozen tiny sort launches per client on a side
     # stream; a process has four hardware queues, the side stream shared one with a
@@ -487,8 +506,7 @@ class MnistCnnNativeTrainer(GroupTrainer):
     def _take_indices(self, round_idx: int, epoch: int) -> None:
         if self._idx_key != (round_idx, epoch):
             self._prefetch_indices(round_idx, epoch)
-        # the caching host allocator keeps the table until the copy has run
-        self.buf.idx.copy_(self._idx_host, non_blocking=True)
+        self._copy_indices(self._idx_host)
         self._idx_host, self._idx_key = None, None
 
     def _ensure_graph(self, round_idx: int) -> None:
