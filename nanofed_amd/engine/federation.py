@@ -1079,6 +1079,7 @@ class FederatedEngine:
 
     def load_global_state_dict(self, state: dict) -> None:
         self.global_arena.load_state_dict(state)
+        self._prelaunched = None  # a round queued early started from the old model
 
     def synchronize(self) -> None:
         if self.device.type == "cuda":

@@ -212,3 +212,19 @@ def test_runs_that_roll_back_or_inject_faults_keep_the_plain_order():
     eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG, sign_updates=True), comm=Communicator())
     assert not eng._may_prefetch()
     assert FederatedEngine(EngineConfig(**_PREFETCH_CFG), comm=Communicator())._may_prefetch()
+
+
+def test_a_new_global_model_drops_the_round_that_was_queued_from_the_old_one():
+    eng = FederatedEngine(EngineConfig(**_PREFETCH_CFG), comm=Communicator())
+    eng.run_round(prefetch_next=True)
+    assert eng._prelaunched is not None
+    fresh = FederatedEngine(EngineConfig(**_PREFETCH_CFG, seed=5), comm=Communicator())
+    eng.load_global_state_dict(fresh.global_state_dict())
+    assert eng._prelaunched is None
+    eng.run_round()
+    # the same as a plain engine that is given that model after its first round
+    ref = FederatedEngine(EngineConfig(**_PREFETCH_CFG, prefetch_rounds=False), comm=Communicator())
+    ref.run_round()
+    ref.load_global_state_dict(fresh.global_state_dict())
+    ref.run_round()
+    assert torch.equal(eng.global_arena.data, ref.global_arena.data)
