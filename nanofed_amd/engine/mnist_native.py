@@ -636,7 +636,10 @@ class MnistCnnNativeTrainer(GroupTrainer):
                 )
                 for k, acc in enumerate(self._accountants)
             ]
-            out[:, M_EPSILON] = torch.tensor(eps, dtype=torch.float32).to(self.device)
+            # from page-locked memory: the copy does not make the host wait for the epochs
+            # queued before it
+            out[:, M_EPSILON].copy_(torch.tensor(eps, dtype=torch.float32).pin_memory(),
+                                    non_blocking=True)
         return out
 
     # -- held-out evaluation ----------------------------------------------

@@ -424,7 +424,10 @@ class TorchGroupTrainer(GroupTrainer):
                 )
                 for k, acc in enumerate(self._accountants)
             ]
-            self.metrics[:, M_EPSILON] = torch.tensor(eps, dtype=torch.float32).to(self.device)
+            host = torch.tensor(eps, dtype=torch.float32)
+            if self.device.type == "cuda":
+                host = host.pin_memory()  # the copy does not wait for the queued steps
+            self.metrics[:, M_EPSILON].copy_(host, non_blocking=True)
         return self.metrics
 
     def _count_steps(self, k: int, steps: int) -> None:
