@@ -164,6 +164,11 @@ class _Watchdog:
         with self._lock:
             self._deadline = None
 
+    def expires_within(self, margin_s: float) -> bool:
+        """Whether the armed round is past its deadline or will be within ``margin_s``."""
+        with self._lock:
+            return self._deadline is not None and time.monotonic() + margin_s > self._deadline
+
     def close(self) -> None:
         self._stop.set()
 
@@ -497,6 +502,16 @@ class FederatedEngine:
             self._watchdog.arm(r)
         try:
             report = self._round(r, t0, start, prefetch_next and self._may_prefetch())
+        except Exception:
+            # A peer whose watchdog fired a moment before ours has left the job, and its
+            # exit surfaces here as a failed collective: that is the same time-out, seen
+            # from the other side - end the same way (FAILED record, exit code for the
+            # supervisor) instead of racing our own watchdog with a traceback.
+            if self._watchdog is not None and self._watchdog.expires_within(
+                min(1.0, max(0.2, 0.1 * self._watchdog.limit_s))
+            ):
+                self._on_round_timeout(r, self._watchdog.limit_s)
+            raise
         finally:
             if self._watchdog is not None:
                 self._watchdog.disarm()

@@ -124,3 +124,43 @@ def test_phase_timer_and_trace_ranges_on_cpu():
     assert set(out) == {"a", "b"} and out["a"] >= 0.0
     assert timer.collect() == {}
     assert isinstance(roctx_available(), bool)
+
+
+def test_a_failed_collective_at_the_deadline_is_the_time_out_not_a_traceback(monkeypatch):
+    """When a peer's watchdog fires a moment before ours, its exit reaches this rank as a
+    failed collective; the round must end as the time-out it is (FAILED record, supervisor
+    exit code), not race the watchdog thread with an exception."""
+    import time as _time
+
+    class TimedOut(Exception):
+        pass
+
+    eng = FederatedEngine(cfg(round_timeout_s=0.6, enforce_round_timeout=True,
+                              first_round_grace_s=0.0), comm=Communicator())
+    seen = []
+
+    def on_timeout(round_id, limit_s):
+        seen.append((round_id, limit_s))
+        raise TimedOut()
+
+    monkeypatch.setattr(eng, "_on_round_timeout", on_timeout)
+    eng._watchdog.close()  # the thread would end the process; the main-thread path is under test
+
+    def peer_left(r, t0, start, prefetch_next=False):
+        _time.sleep(0.5)  # 0.1 s before the deadline
+        raise RuntimeError("Connection closed by peer")
+
+    monkeypatch.setattr(eng, "_round", peer_left)
+    with pytest.raises(TimedOut):
+        eng.run_round()
+    assert seen == [(0, 0.6)]
+
+    # an error early in the window is an error
+    def early(r, t0, start, prefetch_next=False):
+        raise RuntimeError("boom")
+
+    monkeypatch.setattr(eng, "_round", early)
+    with pytest.raises(RuntimeError, match="boom"):
+        eng.run_round()
+    assert len(seen) == 1
+    eng.close()
