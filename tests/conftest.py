@@ -33,6 +33,21 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_runtest_logreport(report):
+    """Keep the full text of every failure in a file as well: a failure that does not
+    come back on the next run (multi-process tests share ports and CPUs with whatever else
+    the machine is doing) can still be read afterwards."""
+    if report.failed:
+        path = os.environ.get("NANOFED_TEST_FAILURE_LOG", "/tmp/nanofed_test_failures.log")
+        try:
+            with open(path, "a") as fh:
+                fh.write(f"==== {report.nodeid} [{report.when}]\n{report.longreprtext}\n")
+                for name, text in report.sections:
+                    fh.write(f"---- {name}\n{text[-4000:]}\n")
+        except OSError:
+            pass
+
+
 @pytest.fixture(autouse=True)
 def _quiet_logger():
     """Keep the framework logger from flooding test output."""
