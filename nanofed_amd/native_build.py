@@ -89,15 +89,21 @@ def _compile_all(
         if _stale(src, obj, _newest_header(src.parent)):
             todo.append((src, obj))
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
-        list(
-            pool.map(
-                lambda so: _run(
-                    [compiler, *flags, "-c", str(so[0]), "-o", str(so[1])]
-                ),
-                todo,
-            )
-        )
+        list(pool.map(lambda so: _produce(so[1], [compiler, *flags, "-c", str(so[0])]), todo))
     return objs, bool(todo)
+
+
+def _produce(target: Path, cmd: list[str]) -> None:
+    """Run ``cmd -o <temporary>`` and move the result into place: a process that loads or
+    links ``target`` meanwhile (a test worker, a second build) sees the old file or the new
+    one, never half of one."""
+    tmp = target.with_name(f".{target.name}.{os.getpid()}.tmp")
+    try:
+        _run([*cmd, "-o", str(tmp)])
+        os.replace(tmp, target)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
 
 
 def build_host(force: bool = False, jobs: int = 4) -> Path:
@@ -108,7 +114,7 @@ def build_host(force: bool = False, jobs: int = 4) -> Path:
             o.unlink()
     objs, changed = _compile_all("g++", HOST_FLAGS, sources, "host", jobs)
     if changed or not HOST_LIB.exists():
-        _run(["g++", "-shared", "-o", str(HOST_LIB), *map(str, objs), "-lcrypto"])
+        _produce(HOST_LIB, ["g++", "-shared", *map(str, objs), "-lcrypto"])
     return HOST_LIB
 
 
@@ -121,10 +127,7 @@ def build_hip(force: bool = False, jobs: int = 4) -> Path:
     hipcc = _hipcc()
     objs, changed = _compile_all(hipcc, HIPCC_FLAGS, sources, "hip", jobs)
     if changed or not HIP_LIB.exists():
-        _run(
-            [hipcc, f"--offload-arch={GPU_ARCH}", "-shared", "-fPIC", "-o",
-             str(HIP_LIB), *map(str, objs)]
-        )
+        _produce(HIP_LIB, [hipcc, f"--offload-arch={GPU_ARCH}", "-shared", "-fPIC", *map(str, objs)])
     return HIP_LIB
 
 
