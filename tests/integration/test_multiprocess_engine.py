@@ -35,6 +35,10 @@ def _env(**extra):
     return env
 
 
+_TRANSPORT_TROUBLE = ("Address already in use", "Connection refused", "Connection reset",
+                      "connect() timed out", "Socket Timeout", "Broken pipe",
+                      "failed to connect", "DistNetworkError", "DistStoreError")
+
 BENCH_ARGS = ["--cpu", "--steps", "2", "--warmup", "1", "--model", "mnist_mlp",
               "--samples-per-client", "64", "--batch-size", "32", "--backend", "torch",
               "--dtype", "fp32", "--eval-samples", "64", "--local-epochs", "1"]
@@ -49,6 +53,10 @@ def _bench(nproc: int, dump: str) -> dict:
                f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    if proc.returncode != 0 and nproc > 1 and any(t in proc.stderr for t in _TRANSPORT_TROUBLE):
+        # the ranks did not get to meet (busy machine, port taken meanwhile): once more
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, f"stdout must carry exactly one line, got {lines!r}"
@@ -138,10 +146,25 @@ def _wait(procs, timeout):
     return codes
 
 
+def _run_ok(tmp_path, nproc, cfg, timeout=300, **kw):
+    """Launch a job that is expected to end with status 0 on every rank.  The ranks meet
+    over local TCP (store + gloo pairs) on a port that was free a few seconds earlier; on a
+    busy machine that meeting can fail for reasons that have nothing to do with the code
+    under test, so a job that died of a transport error is started once more."""
+    for attempt in (0, 1):
+        procs, out = _launch(tmp_path, nproc, cfg, **kw)
+        codes = _wait(procs, timeout)
+        errs = [p.stderr.read() for p in procs]
+        if codes == [0] * nproc:
+            return out
+        if attempt == 0 and any(t in e for e in errs for t in _TRANSPORT_TROUBLE):
+            continue
+        raise AssertionError(f"exit codes {codes}: {[e[-1500:] for e in errs]}")
+    raise AssertionError("unreachable")
+
+
 def test_eight_clients_on_three_ranks_equal_the_single_process_run(tmp_path):
-    procs, out = _launch(tmp_path, 3, BASE_CFG)
-    codes = _wait(procs, 300)
-    assert codes == [0, 0, 0], [p.stderr.read()[-1500:] for p in procs]
+    out = _run_ok(tmp_path, 3, BASE_CFG)
     dist = torch.load(out, weights_only=False)
     single = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
     reps = single.run(2)
@@ -154,9 +177,7 @@ def test_a_failure_on_one_rank_only_is_agreed_on_and_recovered_by_all(tmp_path):
     cfg = dict(BASE_CFG, checkpoint_rounds=True)
     # only rank 1 raises, in the middle of round 1; rank 0 finishes its training
     faults = dict(fail={1: "HIP error: injected on one rank"}, fail_ranks={1})
-    procs, out = _launch(tmp_path, 2, cfg, faults=faults, rounds=3, base=str(tmp_path / "run"))
-    codes = _wait(procs, 300)
-    assert codes == [0, 0], [p.stderr.read()[-1500:] for p in procs]
+    out = _run_ok(tmp_path, 2, cfg, faults=faults, rounds=3, base=str(tmp_path / "run"))
     dist = torch.load(out, weights_only=False)
     assert dist["recoveries"] == 1
     assert dist["rounds"] == [0, 1, 2] and dist["status"] == ["COMPLETED"] * 3
@@ -177,7 +198,7 @@ def test_a_failure_on_one_rank_without_checkpoints_ends_every_rank(tmp_path):
 
 def test_a_stalled_rank_ends_the_job_within_the_timeout_and_resume_continues(tmp_path):
     base = tmp_path / "run"
-    cfg = dict(BASE_CFG, round_timeout_s=3.0, enforce_round_timeout=True, first_round_grace_s=60.0)
+    cfg = dict(BASE_CFG, round_timeout_s=6.0, enforce_round_timeout=True, first_round_grace_s=60.0)
     # rank 1 hangs for two minutes inside round 1; round 0 completes and is saved
     faults = dict(stall={1: {1: 120.0}})
     t0 = time.monotonic()
@@ -190,8 +211,7 @@ def test_a_stalled_rank_ends_the_job_within_the_timeout_and_resume_continues(tmp
     done = json.loads((base / "metrics" / "metrics_round_0.json").read_text())
     assert done["status"] == "COMPLETED"
     # a fresh job resumes after the last completed round
-    procs, out = _launch(tmp_path, 2, BASE_CFG, rounds=2, base=str(base), resume=True, name="again")
-    assert _wait(procs, 300) == [0, 0]
+    out = _run_ok(tmp_path, 2, BASE_CFG, rounds=2, base=str(base), resume=True, name="again")
     again = torch.load(out, weights_only=False)
     assert again["rounds"] == [1, 2] and again["status"] == ["COMPLETED"] * 2
     clean = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
