@@ -194,9 +194,9 @@ def main() -> int:
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
     engine.close()
-    comm.close()
     if scratch is not None:
         shutil.rmtree(scratch, ignore_errors=True)
+    comm.finish(0)  # multi-process: leaves here, past the libraries' exit handlers
     return 0
 
 

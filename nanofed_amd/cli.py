@@ -110,7 +110,8 @@ def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_c
             click.echo(json.dumps(line))
     if comm.is_root:
         click.echo(json.dumps({"eval": engine.evaluate()}))
-    comm.close()
+    engine.close()
+    comm.finish(0)  # several ranks: leaves here, past the libraries' exit handlers
 
 
 @main.command(context_settings={"ignore_unknown_options": True})

@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 if comm.is_root:
     torch.save({{"flat": eng.global_arena.data.cpu(), "loss": reps[-1].agg_metrics["loss"],
                 "weights": [c["weight"] for c in reps[-1].client_metrics]}}, {out!r})
-comm.close()
+comm.finish(0)
 """
 
 
@@ -88,7 +88,7 @@ t = comm.max_over_ranks(1.5)
 torch.cuda.synchronize()
 torch.save({{"flat": eng.global_arena.data.cpu(), "loss": reps[-1].agg_metrics["loss"], "max": t}},
            {out!r})
-comm.close()
+comm.finish(0)
 """
 
 

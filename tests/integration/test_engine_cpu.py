@@ -124,7 +124,7 @@ reps = eng.run(2)
 if comm.is_root:
     torch.save({{"flat": eng.global_arena.data, "loss": reps[-1].agg_metrics["loss"],
                 "n": reps[-1].num_clients}}, {out!r})
-comm.close()
+comm.finish(0)
 """
 
 

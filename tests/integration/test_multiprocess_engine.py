@@ -109,7 +109,7 @@ if comm.is_root:
                 "weights": [c["weight"] for c in reps[-1].client_metrics],
                 "loss": reps[-1].agg_metrics["loss"]}}, {out!r})
 eng.close()
-comm.close()
+comm.finish(0)
 """
 
 BASE_CFG = dict(model="mnist_mlp", num_clients=8, samples_per_client=[96, 64, 64, 32, 64, 64, 96, 32],
