@@ -37,7 +37,9 @@ def _env(**extra):
 
 _TRANSPORT_TROUBLE = ("Address already in use", "Connection refused", "Connection reset",
                       "connect() timed out", "Socket Timeout", "Broken pipe",
-                      "failed to connect", "DistNetworkError", "DistStoreError")
+                      "failed to connect", "DistNetworkError", "DistStoreError",
+                      # a library helper thread that aborts a finished process at exit
+                      "terminate called without an active exception")
 
 BENCH_ARGS = ["--cpu", "--steps", "2", "--warmup", "1", "--model", "mnist_mlp",
               "--samples-per-client", "64", "--batch-size", "32", "--backend", "torch",
