@@ -57,7 +57,8 @@ def main() -> None:
                               **report.agg_metrics, "wall_s": round(report.wall_s, 3)}))
     if comm.is_root:
         print(json.dumps({"eval": engine.evaluate()}))
-    comm.close()
+    engine.close()
+    comm.finish()  # under a launcher (several ranks) the process leaves here
 
 
 if __name__ == "__main__":
