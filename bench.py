@@ -73,6 +73,7 @@ def main() -> int:
     ap.add_argument("--cpu", action="store_true", help="run on CPU/gloo (plumbing check)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not queue the next round before the host has finished the current one")
+    ap.add_argument("--verbose", action="store_true", help="keep the INFO/DEBUG log lines")
     ap.add_argument("--no-persist", action="store_true",
                     help="leave the per-round model version / metrics files out of the timed rounds")
     ap.add_argument("--eval-samples", type=int, default=10000)
@@ -90,6 +91,11 @@ def main() -> int:
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if not args.verbose:
+        # three log lines per saved round are formatted on the writer thread otherwise
+        from nanofed_amd.utils import LogConfig, Logger, LogLevel
+
+        Logger().configure(LogConfig(level=LogLevel.WARNING))
     # keep the collective library quiet on stdout (rank 0 prints exactly one JSON line)
     os.environ.setdefault("NCCL_DEBUG", "WARN")
     world = int(os.environ.get("WORLD_SIZE", "1"))
