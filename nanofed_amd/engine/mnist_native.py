@@ -332,7 +332,8 @@ class NativeBuffers:
 
 class MnistCnnNativeTrainer(GroupTrainer):
     make_layout = staticmethod(make_layout)
-    STREAM_TRIALS = 4  # epochs spent choosing the group streams
+    # epochs spent choosing the group streams (NANOFED_MNIST_STREAM_TRIALS: measurements)
+    STREAM_TRIALS = max(1, int(os.environ.get("NANOFED_MNIST_STREAM_TRIALS", "4")))
     HEAD_STEPS = 8     # steps in the short first graph of a group's epoch
 
     def __init__(

@@ -12,10 +12,16 @@ from nanofed_amd.engine import EngineConfig, FederatedEngine  # noqa: E402
 from nanofed_amd.parallel import Communicator  # noqa: E402
 
 torch.cuda.set_device(0)
+extra = {}
+if "--dp" in sys.argv:  # the non-IID DP-SGD configuration of benchmarks/run_configs.py
+    from nanofed_amd.engine import DPConfig
+
+    extra = dict(partition="dirichlet", dirichlet_alpha=0.1,
+                 dp=DPConfig(max_gradient_norm=1.0, noise_multiplier=1.1))
 cfg = EngineConfig(model="mnist_cnn", num_clients=8, samples_per_client=7500, batch_size=64,
                    local_epochs=2, learning_rate=0.1, eval_samples=1000,
                    prefetch_rounds="--no-prefetch" not in sys.argv,
-                   dataset="synthetic_mnist_hard")
+                   dataset="synthetic_mnist_hard", **extra)
 eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
 eng.run(3)
 tr = eng.trainer
