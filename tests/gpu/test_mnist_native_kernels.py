@@ -381,6 +381,34 @@ def test_client_groups_train_the_same_model(monkeypatch):
     assert outs[0][1] == outs[1][1]
 
 
+@pytest.mark.parametrize("clients", [1, 2])
+def test_three_backward_kernels_in_one_launch_train_the_same_model(monkeypatch, clients):
+    """conv2_dgrad, fc1_wgrad and conv2_wgrad only need what fc1_dgrad left behind; with
+    one client on the GPU they share a launch (conv2_wgrad is written for six waves, the
+    others retire the two spare waves at once).  Same bodies, same order of additions:
+    the models agree bit for bit with the two-launch sequence."""
+    from nanofed_amd.engine import EngineConfig, FederatedEngine
+    from nanofed_amd.parallel import Communicator
+
+    outs = []
+    for triple in ("1", "0"):
+        monkeypatch.setenv("NANOFED_MNIST_TRIPLE", triple)
+        torch.cuda.set_device(0)
+        cfg = EngineConfig(model="mnist_cnn", num_clients=clients, samples_per_client=320,
+                           batch_size=64, local_epochs=2, eval_samples=64, backend="native", seed=9,
+                           client_streams=False)
+        eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
+        assert eng.trainer.buf.ctx.bwd_triple == int(triple)
+        reps = eng.run(2)
+        outs.append((eng.global_arena.data.clone(), [r.agg_metrics for r in reps]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    # the default: on with one client on the GPU, off otherwise
+    monkeypatch.delenv("NANOFED_MNIST_TRIPLE")
+    eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
+    assert eng.trainer.buf.ctx.bwd_triple == int(clients == 1)
+
+
 def test_make_streams_returns_usable_streams():
     from nanofed_amd.utils.streams import make_streams
 
