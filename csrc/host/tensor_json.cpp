@@ -54,6 +54,97 @@ void encode_rec(Writer& w, const float*& data, const long* shape, int ndim) {
     w.put(']');
 }
 
+// The same text written without a bounds check per character: the caller has room for
+// nf_json_encode_bound() bytes (20 per number: at most 15 of digits / sign / point /
+// exponent, ".0", ", " and slack for brackets).
+inline char* number_fast(char* p, float v) {
+    if (__builtin_expect(!std::isfinite(v), 0)) {
+        const char* s = std::isnan(v) ? "NaN" : (v > 0 ? "Infinity" : "-Infinity");
+        while (*s) *p++ = *s++;
+        return p;
+    }
+    char* const first = p;
+    p = std::to_chars(p, p + 24, v).ptr;
+    bool is_int = true;
+    for (const char* q = first; q != p; ++q)
+        if (*q == '.' || *q == 'e') { is_int = false; break; }
+    if (is_int) { *p++ = '.'; *p++ = '0'; }  // keep it a JSON float, as tolist() would
+    return p;
+}
+
+char* encode_fast(char* p, const float*& data, const long* shape, int ndim) {
+    if (ndim == 0) return number_fast(p, *data++);
+    *p++ = '[';
+    if (ndim == 1) {
+        const long n = shape[0];
+        const float* d = data;
+        for (long i = 0; i < n; ++i) {
+            if (i) { *p++ = ','; *p++ = ' '; }
+            p = number_fast(p, d[i]);
+        }
+        data += n;
+    } else {
+        for (long i = 0; i < shape[0]; ++i) {
+            if (i) { *p++ = ','; *p++ = ' '; }
+            p = encode_fast(p, data, shape + 1, ndim - 1);
+        }
+    }
+    *p++ = ']';
+    return p;
+}
+
+// Exact powers of ten in double: 10^0 .. 10^22.
+const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// Decimal text -> double for the common case (at most 15 significant digits in total,
+// decimal exponent within +-22): significand and power of ten are both exact doubles, so
+// one multiplication or division gives the correctly rounded result - what from_chars
+// returns, far faster.  Returns nullptr when the text is not of that form (the caller
+// falls back to from_chars).
+inline const char* parse_fast(const char* p, const char* end, double* out) {
+    const char* q = p;
+    bool neg = false;
+    if (q < end && *q == '-') { neg = true; ++q; }
+    uint64_t mant = 0;
+    int digits = 0, frac = 0;
+    bool any = false, nonzero = false;
+    while (q < end && *q >= '0' && *q <= '9') {
+        any = true;
+        if (nonzero || *q != '0') { nonzero = true; mant = mant * 10 + static_cast<uint64_t>(*q - '0'); ++digits; }
+        ++q;
+    }
+    if (q < end && *q == '.') {
+        ++q;
+        while (q < end && *q >= '0' && *q <= '9') {
+            any = true;
+            if (nonzero || *q != '0') { nonzero = true; mant = mant * 10 + static_cast<uint64_t>(*q - '0'); ++digits; }
+            ++frac;
+            ++q;
+        }
+    }
+    if (!any || digits > 15) return nullptr;
+    int exp10 = 0;
+    if (q < end && (*q == 'e' || *q == 'E')) {
+        ++q;
+        bool eneg = false;
+        if (q < end && (*q == '+' || *q == '-')) { eneg = *q == '-'; ++q; }
+        if (q >= end || *q < '0' || *q > '9') return nullptr;
+        int e = 0;
+        while (q < end && *q >= '0' && *q <= '9') {
+            if (e < 10000) e = e * 10 + (*q - '0');
+            ++q;
+        }
+        exp10 = eneg ? -e : e;
+    }
+    exp10 -= frac;
+    double d = static_cast<double>(mant);
+    if (exp10 < -22 || exp10 > 22) return nullptr;
+    d = exp10 < 0 ? d / kPow10[-exp10] : d * kPow10[exp10];
+    *out = neg ? -d : d;
+    return q;
+}
+
 struct Reader {
     const char* p;
     const char* end;
@@ -110,9 +201,13 @@ struct Reader {
             return;
         if (literal("true", 1.0f) || literal("false", 0.0f)) return;
         double d = 0;
-        auto r = std::from_chars(p, end, d);
-        if (r.ec != std::errc()) { fail = true; return; }
-        p = r.ptr;
+        if (const char* q = parse_fast(p, end, &d)) {
+            p = q;
+        } else {
+            auto r = std::from_chars(p, end, d);
+            if (r.ec != std::errc()) { fail = true; return; }
+            p = r.ptr;
+        }
         emit(static_cast<float>(d));
     }
 };
@@ -129,8 +224,14 @@ long nf_json_encode_bound(long numel, int ndim) {
 // Returns bytes written, or -needed when cap is too small.
 long nf_json_encode_f32(const float* data, const long* shape, int ndim,
                         char* out, long cap) {
-    Writer w{out, cap};
     const float* cursor = data;
+    // unchecked writes when the text certainly fits: at most 17 bytes per number (15 of
+    // digits, ", ") and 4 per list ("[", "]", ", ")
+    long numel = 1, lists = 0;
+    for (int i = 0; i < ndim; ++i) { lists += numel; numel *= shape[i]; }
+    if (cap >= numel * 17 + lists * 4 + 8)
+        return encode_fast(out, cursor, shape, ndim) - out;
+    Writer w{out, cap};
     encode_rec(w, cursor, shape, ndim);
     return w.overflow ? -w.pos : w.pos;
 }

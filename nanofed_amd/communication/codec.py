@@ -43,7 +43,7 @@ def _lib() -> ctypes.CDLL:
         c_void_p, POINTER(c_long), c_int, c_void_p, c_long]
     lib.nf_json_decode_f32.restype = c_long
     lib.nf_json_decode_f32.argtypes = [
-        c_char_p, c_long, c_void_p, c_long, POINTER(c_long), POINTER(c_int),
+        c_void_p, c_long, c_void_p, c_long, POINTER(c_long), POINTER(c_int),
         POINTER(c_long)]
     lib.nf_json_skip_value.restype = c_long
     lib.nf_json_skip_value.argtypes = [c_char_p, c_long, c_long]
@@ -60,9 +60,9 @@ def native_available() -> bool:
 
 def encode_tensor_json(tensor: torch.Tensor) -> bytes:
     """Nested-list JSON text of ``tensor`` (as fp32; integers keep a ``.0``)."""
-    arr = np.ascontiguousarray(
-        tensor.detach().to("cpu", torch.float32).numpy()
-    )
+    arr = tensor.detach().to("cpu", torch.float32).numpy()
+    # (ascontiguousarray alone would turn a 0-d tensor into a list of one number)
+    arr = np.ascontiguousarray(arr).reshape(arr.shape)
     lib = _lib()
     shape = (c_long * max(arr.ndim, 1))(*arr.shape)
     cap = int(lib.nf_json_encode_bound(arr.size, arr.ndim))
@@ -79,26 +79,29 @@ def encode_tensor_json(tensor: torch.Tensor) -> bytes:
 
 
 def _decode_prefix(text: bytes, pos: int) -> tuple[torch.Tensor, int]:
-    """Decode the JSON value starting at ``text[pos]``; returns (tensor, end)."""
+    """Decode the JSON value starting at ``text[pos]``; returns (tensor, end).  The text
+    is parsed in place (no scan for the value's end first, no copy of the value)."""
     lib = _lib()
-    end = int(lib.nf_json_skip_value(text, len(text), pos))
-    if end < 0:
+    remaining = len(text) - pos
+    if remaining <= 0:
         raise ValueError("Truncated JSON value in model_state")
-    piece = text[pos:end]
-    # a number takes at least 2 bytes ("0,") so len/2 bounds the value count
-    cap = len(piece) // 2 + 2
+    # a number takes at least 2 bytes ("0,") so len/2 bounds the value count (the buffer
+    # is only touched where values land)
+    cap = remaining // 2 + 2
     out = np.empty(cap, dtype=np.float32)
     shape = (c_long * 8)()
     ndim = c_int(0)
+    consumed = c_long(0)
+    base = ctypes.cast(ctypes.c_char_p(text), c_void_p).value
     n = lib.nf_json_decode_f32(
-        piece, len(piece), out.ctypes.data_as(c_void_p), cap, shape,
-        ctypes.byref(ndim), None,
+        c_void_p(base + pos), remaining, out.ctypes.data_as(c_void_p), cap, shape,
+        ctypes.byref(ndim), ctypes.byref(consumed),
     )
     if n < 0 or n > cap:
         raise ValueError("Malformed tensor in model_state")
     dims = tuple(int(shape[i]) for i in range(ndim.value))
     tensor = torch.from_numpy(out[:n].copy()).reshape(dims)
-    return tensor, end
+    return tensor, pos + int(consumed.value)
 
 
 def encode_state_json(state: dict[str, Any]) -> bytes:
@@ -113,15 +116,16 @@ def encode_state_json(state: dict[str, Any]) -> bytes:
     return b"{" + b", ".join(parts) + b"}"
 
 
-def decode_state_json(text: bytes) -> dict[str, torch.Tensor]:
-    """Inverse of :func:`encode_state_json` for list-valued states."""
-    pos = text.find(b"{")
+def decode_state_json(text: bytes, start: int = 0, stop: int | None = None) -> dict[str, torch.Tensor]:
+    """Inverse of :func:`encode_state_json` for list-valued states: the JSON object in
+    ``text[start:stop]``, parsed in place."""
+    n = len(text) if stop is None else stop
+    pos = text.find(b"{", start, n)
     if pos < 0:
         raise ValueError("model_state is not a JSON object")
     pos += 1
     lib = _lib()
     state: dict[str, torch.Tensor] = {}
-    n = len(text)
     while True:
         while pos < n and text[pos : pos + 1] in b" \n\t\r,":
             pos += 1
@@ -133,25 +137,49 @@ def decode_state_json(text: bytes) -> dict[str, torch.Tensor]:
         if key_end < 0 or text[pos : pos + 1] != b'"':
             raise ValueError("Malformed key in model_state")
         key = json.loads(text[pos:key_end])
-        pos = text.find(b":", key_end) + 1
+        pos = text.find(b":", key_end, n) + 1
         if pos <= 0:
             raise ValueError("Missing ':' in model_state")
         tensor, pos = _decode_prefix(text, pos)
+        if pos > n:
+            raise ValueError("Truncated JSON value in model_state")
         state[key] = tensor
+
+
+class EncodedState:
+    """The JSON text of a ``model_state`` that has been encoded already (a server hands the
+    same global model to every client of a round: one encoding, many responses)."""
+
+    __slots__ = ("text",)
+
+    def __init__(self, text: bytes) -> None:
+        self.text = text
+
+
+def state_fingerprint(state: dict[str, Any]) -> tuple:
+    """Changes whenever a tensor of ``state`` is replaced or written in place (storage
+    address, shape and PyTorch's in-place version counter of every entry)."""
+    return tuple(
+        (k, v.data_ptr(), tuple(v.shape), v._version) if isinstance(v, torch.Tensor) else (k, id(v))
+        for k, v in state.items()
+    )
 
 
 def dumps_envelope(payload: dict[str, Any]) -> bytes:
     """JSON body for ``payload``; a tensor-valued ``model_state`` entry is
-    encoded natively, everything else with ``json``."""
+    encoded natively (or taken as it is from an ``EncodedState``), everything else with
+    ``json``."""
     state = payload.get("model_state")
-    if not isinstance(state, dict) or not native_available():
+    if isinstance(state, EncodedState):
+        encoded = state.text
+    elif isinstance(state, dict) and native_available():
+        encoded = encode_state_json(state)
+    else:
         return json.dumps(_plain(payload)).encode()
     shell = dict(payload)
     shell["model_state"] = _PLACEHOLDER
     text = json.dumps(_plain(shell)).encode()
-    return text.replace(
-        json.dumps(_PLACEHOLDER).encode(), encode_state_json(state), 1
-    )
+    return text.replace(json.dumps(_PLACEHOLDER).encode(), encoded, 1)
 
 
 def loads_envelope(body: bytes) -> dict[str, Any]:
@@ -173,13 +201,14 @@ def loads_envelope(body: bytes) -> dict[str, Any]:
     end = int(lib.nf_json_skip_value(body, len(body), colon + 1))
     if end < 0:
         raise ValueError("Truncated model_state")
-    value = body[colon + 1 : end]
     envelope = json.loads(body[: colon + 1] + b" null" + body[end:])
-    stripped = value.strip()
-    if stripped.startswith(b"{"):
-        envelope["model_state"] = decode_state_json(value)
+    first = colon + 1
+    while first < end and body[first : first + 1] in b" \n\t\r":
+        first += 1
+    if body[first : first + 1] == b"{":
+        envelope["model_state"] = decode_state_json(body, first, end)
     else:
-        envelope["model_state"] = json.loads(value)
+        envelope["model_state"] = json.loads(body[colon + 1 : end])
     return envelope
 
 

@@ -226,3 +226,34 @@ def test_codec_round_trip_matches_plain_json():
     got = codec.loads_envelope(other)
     assert torch.equal(torch.as_tensor(got["model_state"]["w"], dtype=torch.float32),
                        torch.tensor([[1, 2.5], [3e-3, -4]]))
+
+
+def test_server_encodes_the_global_model_once_until_it_changes():
+    """Every client of a round fetches the same model: the JSON text is kept and only
+    rebuilt when a tensor of the model is replaced or written in place."""
+    import torch
+    import torch.nn as nn
+
+    from nanofed_amd.communication import codec
+    from nanofed_amd.communication.http.server import HTTPServer
+
+    server = HTTPServer("127.0.0.1", 0)
+    model = nn.Linear(4, 2)
+    first = server._encoded_model(model)
+    again = server._encoded_model(model)
+    assert isinstance(first, codec.EncodedState) and again.text is first.text
+    body = codec.dumps_envelope({"status": "success", "model_state": first, "round_number": 3})
+    back = codec.loads_envelope(body)
+    assert back["round_number"] == 3
+    assert torch.equal(back["model_state"]["weight"], model.weight.detach())
+    with torch.no_grad():
+        model.weight.add_(1.0)  # in place: same storage, new version counter
+    changed = server._encoded_model(model)
+    assert changed.text is not first.text
+    back = codec.loads_envelope(codec.dumps_envelope({"model_state": changed}))
+    assert torch.equal(back["model_state"]["weight"], model.weight.detach())
+    model.load_state_dict({k: v * 0 for k, v in model.state_dict().items()})
+    zero = server._encoded_model(model)
+    assert zero.text is not changed.text
+    back = codec.loads_envelope(codec.dumps_envelope({"model_state": zero}))
+    assert float(back["model_state"]["weight"].abs().sum()) == 0.0

@@ -97,3 +97,48 @@ def test_philox_stream_is_a_pure_function_of_seed_offset_and_index(n, cut, seed,
         ops.philox_fill(parts[cut:], seed=seed, offset=offset, mode=mode, first=cut)
     assert torch.equal(whole, parts)
     assert torch.isfinite(whole).all()
+
+
+def test_codec_is_bit_exact_on_every_kind_of_float32_and_parses_like_python():
+    """Random bit patterns (subnormals, extremes, negative zero), the non-finite values, and
+    arbitrary decimal text: the unchecked writer and the short-cut number parser give what the
+    general paths give."""
+    import random
+    import struct
+
+    from nanofed_amd.communication.codec import _decode_prefix
+
+    rng = random.Random(7)
+    values = [0.0, -0.0, 1.0, -1.0, 1e-45, 1.17549435e-38, 3.4028235e38, -3.4028235e38, 0.1,
+              1 / 3, 123456.789, 1e10, 1e-10, 16777216.0, float("nan"), float("inf"), -float("inf")]
+    values += [struct.unpack("f", struct.pack("I", rng.getrandbits(32)))[0] for _ in range(50000)]
+    t = torch.tensor(values, dtype=torch.float32)
+    bits = t.view(torch.int32)
+    nan = torch.isnan(t)
+    text = encode_tensor_json(t)
+    ref = torch.tensor([float(x) for x in json.loads(text, parse_constant=float)],
+                       dtype=torch.float32)
+    assert bool(((ref.view(torch.int32) == bits) | nan).all())
+    back, end = _decode_prefix(text, 0)
+    assert end == len(text) and bool(((back.view(torch.int32) == bits) | nan).all())
+    assert bool((torch.isnan(back) == nan).all())
+    # decimal text that no float32 printer wrote: 1-17 digits, exponents far out
+    texts = ["%.*g" % (rng.randint(1, 17), rng.uniform(-1, 1) * 10 ** rng.randint(-40, 39))
+             for _ in range(20000)] + ["1e-50", "-1e60", "0.000000000000000000001", "12345678901234567890"]
+    blob = ("[" + ", ".join(texts) + "]").encode()
+    got, _ = _decode_prefix(blob, 0)
+    want = torch.tensor([float(x) for x in texts], dtype=torch.float64).to(torch.float32)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+def test_codec_writes_the_lists_python_would_for_degenerate_shapes():
+    for shape in [(5, 1, 1), (3, 0), (0,), (2, 2, 2, 1), (1, 1, 1, 1, 3), ()]:
+        n = int(np.prod(shape)) if shape else 1
+        x = torch.arange(n, dtype=torch.float32).reshape(shape)
+        assert json.loads(encode_tensor_json(x)) == x.tolist(), shape
+    # a 0-d entry (BatchNorm's num_batches_tracked) is a plain number on the wire, as
+    # tensor.tolist() makes it, and comes back 0-d
+    body = dumps_envelope({"model_state": {"w": torch.ones(2, 2), "n": torch.tensor(7)}})
+    assert b'"n": 7.0' in body
+    back = loads_envelope(body)
+    assert back["model_state"]["n"].shape == () and float(back["model_state"]["n"]) == 7.0
