@@ -18,6 +18,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -91,6 +94,45 @@ char* encode_fast(char* p, const float*& data, const long* shape, int ndim) {
     }
     *p++ = ']';
     return p;
+}
+
+// Large tensors: the rows of the outermost dimension are cut into contiguous ranges, one
+// per thread; every thread writes its rows (", " between them) into a buffer of its own
+// and the pieces are joined.  The text is the same as the single-threaded one.
+long encode_parallel(char* out, const float* data, const long* shape, int ndim, int threads) {
+    const long rows = shape[0];
+    long row_numel = 1, row_lists = 0;
+    for (int i = 1; i < ndim; ++i) { row_lists += row_numel; row_numel *= shape[i]; }
+    const long row_bound = row_numel * 17 + row_lists * 4 + 8;
+    std::vector<std::vector<char>> piece(threads);
+    std::vector<long> used(threads, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const long r0 = rows * t / threads, r1 = rows * (t + 1) / threads;
+        pool.emplace_back([&, t, r0, r1] {
+            piece[t].resize(static_cast<size_t>((r1 - r0) * row_bound + 8));
+            char* p = piece[t].data();
+            const float* cursor = data + r0 * row_numel;
+            for (long r = r0; r < r1; ++r) {
+                if (r != r0) { *p++ = ','; *p++ = ' '; }
+                p = encode_fast(p, cursor, shape + 1, ndim - 1);
+            }
+            used[t] = p - piece[t].data();
+        });
+    }
+    for (auto& th : pool) th.join();
+    char* p = out;
+    *p++ = '[';
+    bool first = true;
+    for (int t = 0; t < threads; ++t) {
+        if (used[t] == 0) continue;
+        if (!first) { *p++ = ','; *p++ = ' '; }
+        first = false;
+        std::memcpy(p, piece[t].data(), static_cast<size_t>(used[t]));
+        p += used[t];
+    }
+    *p++ = ']';
+    return p - out;
 }
 
 // Exact powers of ten in double: 10^0 .. 10^22.
@@ -212,6 +254,76 @@ struct Reader {
     }
 };
 
+// A large two-dimensional list: find the rows (memchr for their closing brackets), let a
+// few threads parse contiguous ranges of rows into buffers of their own, join.  Returns
+// false when the text is not of that plain form (the caller parses it sequentially, which
+// also produces the error for malformed input).
+bool decode_rows_parallel(const char* text, const char* end, float* out, long cap, long* count_out,
+                          long* rows_out, long* cols_out, const char** after, int threads) {
+    auto skip_ws = [&](const char* p) {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+        return p;
+    };
+    const char* p = skip_ws(text);
+    if (p >= end || *p != '[') return false;
+    p = skip_ws(p + 1);
+    std::vector<std::pair<const char*, const char*>> rows;
+    for (;;) {
+        if (p >= end || *p != '[') return false;
+        const char* close = static_cast<const char*>(std::memchr(p + 1, ']', static_cast<size_t>(end - p - 1)));
+        if (close == nullptr) return false;
+        if (std::memchr(p + 1, '[', static_cast<size_t>(close - p - 1)) != nullptr) return false;  // deeper nesting
+        if (std::memchr(p + 1, '"', static_cast<size_t>(close - p - 1)) != nullptr) return false;
+        rows.emplace_back(p, close + 1);
+        p = skip_ws(close + 1);
+        if (p < end && *p == ',') { p = skip_ws(p + 1); continue; }
+        if (p < end && *p == ']') { ++p; break; }
+        return false;
+    }
+    const long nrows = static_cast<long>(rows.size());
+    if (nrows < threads) return false;
+    std::vector<std::vector<float>> piece(threads);
+    std::vector<long> counts(threads, 0), cols(threads, -1);
+    std::vector<char> bad(threads, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const long i0 = nrows * t / threads, i1 = nrows * (t + 1) / threads;
+        pool.emplace_back([&, t, i0, i1] {
+            const long bytes = rows[i1 - 1].second - rows[i0].first;
+            piece[t].resize(static_cast<size_t>(bytes / 2 + 2));
+            Reader r{rows[i0].first, rows[i0].second, piece[t].data(), static_cast<long>(piece[t].size())};
+            for (int i = 0; i < 8; ++i) { r.seen[i] = false; r.shape[i] = 0; }
+            for (long i = i0; i < i1; ++i) {
+                r.p = rows[i].first;
+                r.end = rows[i].second;
+                r.value(1);
+                if (r.fail || r.p != rows[i].second) { bad[t] = 1; return; }
+            }
+            counts[t] = r.count;
+            cols[t] = r.seen[1] ? r.shape[1] : 0;
+            if (r.max_depth > 2) bad[t] = 1;
+        });
+    }
+    for (auto& th : pool) th.join();
+    long total = 0;
+    for (int t = 0; t < threads; ++t) {
+        if (bad[t] || cols[t] != cols[0]) return false;
+        total += counts[t];
+    }
+    if (total <= cap) {
+        float* dst = out;
+        for (int t = 0; t < threads; ++t) {
+            std::memcpy(dst, piece[t].data(), static_cast<size_t>(counts[t]) * sizeof(float));
+            dst += counts[t];
+        }
+    }
+    *count_out = total;
+    *rows_out = nrows;
+    *cols_out = cols[0];
+    *after = p;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -229,8 +341,15 @@ long nf_json_encode_f32(const float* data, const long* shape, int ndim,
     // digits, ", ") and 4 per list ("[", "]", ", ")
     long numel = 1, lists = 0;
     for (int i = 0; i < ndim; ++i) { lists += numel; numel *= shape[i]; }
-    if (cap >= numel * 17 + lists * 4 + 8)
+    if (cap >= numel * 17 + lists * 4 + 8) {
+        // worth a few threads from about a quarter of a million numbers on
+        if (ndim >= 2 && numel >= (1L << 18) && shape[0] >= 8) {
+            unsigned hw = std::thread::hardware_concurrency();
+            int threads = static_cast<int>(hw == 0 ? 4 : (hw > 8 ? 8 : hw));
+            if (threads > 1) return encode_parallel(out, data, shape, ndim, threads);
+        }
         return encode_fast(out, cursor, shape, ndim) - out;
+    }
     Writer w{out, cap};
     encode_rec(w, cursor, shape, ndim);
     return w.overflow ? -w.pos : w.pos;
@@ -246,6 +365,26 @@ long nf_json_encode_f32(const float* data, const long* shape, int ndim,
 // there and whatever follows is left to the caller.
 long nf_json_decode_f32(const char* text, long len, float* out, long cap,
                         long* shape_out, int* ndim_out, long* consumed_out) {
+    if (len >= (1L << 21)) {  // worth a few threads from a couple of megabytes on
+        unsigned hw = std::thread::hardware_concurrency();
+        const int threads = static_cast<int>(hw == 0 ? 4 : (hw > 8 ? 8 : hw));
+        long count = 0, rows = 0, cols = 0;
+        const char* after = nullptr;
+        if (threads > 1 && decode_rows_parallel(text, text + len, out, cap, &count, &rows, &cols,
+                                                &after, threads)) {
+            if (consumed_out) {
+                *consumed_out = after - text;
+            } else {
+                const char* q = after;
+                while (q < text + len && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) ++q;
+                if (q != text + len) return -1;
+            }
+            *ndim_out = 2;
+            shape_out[0] = rows;
+            shape_out[1] = cols;
+            return count;
+        }
+    }
     Reader r{text, text + len, out, cap};
     for (int i = 0; i < 8; ++i) { r.seen[i] = false; r.shape[i] = 0; }
     r.value(0);

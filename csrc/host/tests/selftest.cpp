@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 extern "C" {
@@ -89,6 +90,42 @@ static void test_json() {
     CHECK(nf_json_skip_value(obj, static_cast<long>(std::strlen(obj)), 0) == 32);
     CHECK(nf_json_skip_value("\"open", 5, 0) == -1);
     CHECK(nf_json_skip_value("[1,2", 4, 0) == -1);
+
+    // large tensors take the threaded paths (rows split over threads): same text, same
+    // values, trailing text left alone, truncation and ragged rows rejected
+    const long R = 96, C = 4096;
+    std::vector<float> big(static_cast<size_t>(R * C));
+    for (long i = 0; i < R * C; ++i) big[i] = 0.001f * static_cast<float>(i % 9973) - 3.25f;
+    big[5] = std::numeric_limits<float>::quiet_NaN();
+    big[C + 1] = -std::numeric_limits<float>::infinity();
+    const long bshape[2] = {R, C};
+    const long bbound = nf_json_encode_bound(R * C, 2);
+    std::vector<char> btext(static_cast<size_t>(bbound) + 8);
+    const long bn = nf_json_encode_f32(big.data(), bshape, 2, btext.data(), bbound);
+    CHECK(bn > (1L << 21));
+    std::vector<char> exact(static_cast<size_t>(bn));
+    CHECK(nf_json_encode_f32(big.data(), bshape, 2, exact.data(), bn) == bn);  // checked writer
+    CHECK(std::memcmp(exact.data(), btext.data(), static_cast<size_t>(bn)) == 0);
+    std::vector<float> bback(static_cast<size_t>(R * C));
+    CHECK(nf_json_decode_f32(btext.data(), bn, bback.data(), R * C, shp, &ndim, nullptr) == R * C);
+    CHECK(ndim == 2 && shp[0] == R && shp[1] == C);
+    for (long i = 0; i < R * C; ++i)
+        CHECK(std::memcmp(&bback[i], &big[i], 4) == 0 || (big[i] != big[i] && bback[i] != bback[i]));
+    std::memcpy(btext.data() + bn, ", 7", 3);
+    CHECK(nf_json_decode_f32(btext.data(), bn + 3, bback.data(), R * C, shp, &ndim, &used) == R * C);
+    CHECK(used == bn);
+    CHECK(nf_json_decode_f32(btext.data(), bn - 1, bback.data(), R * C, shp, &ndim, nullptr) == -1);
+    CHECK(nf_json_decode_f32(btext.data(), bn, bback.data(), 10, shp, &ndim, nullptr) == R * C);
+    // drop one number from a row in the middle: ragged
+    {
+        std::vector<char> rag(btext.begin(), btext.begin() + bn);
+        long at = bn / 2;
+        while (rag[at] != ',') ++at;
+        long stop = at + 1;
+        while (rag[stop] != ',' && rag[stop] != ']') ++stop;
+        for (long i = at; i < stop; ++i) rag[i] = ' ';
+        CHECK(nf_json_decode_f32(rag.data(), bn, bback.data(), R * C, shp, &ndim, nullptr) == -1);
+    }
 }
 
 static void test_aes() {

@@ -40,7 +40,7 @@ def _lib() -> ctypes.CDLL:
     lib.nf_json_encode_bound.argtypes = [c_long, c_int]
     lib.nf_json_encode_f32.restype = c_long
     lib.nf_json_encode_f32.argtypes = [
-        c_void_p, POINTER(c_long), c_int, c_void_p, c_long]
+        c_void_p, POINTER(c_long), c_int, c_void_p, c_long]  # data, shape, ndim, out, cap
     lib.nf_json_decode_f32.restype = c_long
     lib.nf_json_decode_f32.argtypes = [
         c_void_p, c_long, c_void_p, c_long, POINTER(c_long), POINTER(c_int),
@@ -58,24 +58,41 @@ def native_available() -> bool:
         return False
 
 
-def encode_tensor_json(tensor: torch.Tensor) -> bytes:
-    """Nested-list JSON text of ``tensor`` (as fp32; integers keep a ``.0``)."""
+def _as_f32_array(tensor: torch.Tensor) -> np.ndarray:
     arr = tensor.detach().to("cpu", torch.float32).numpy()
     # (ascontiguousarray alone would turn a 0-d tensor into a list of one number)
-    arr = np.ascontiguousarray(arr).reshape(arr.shape)
+    return np.ascontiguousarray(arr).reshape(arr.shape)
+
+
+def _encode_into(arr: np.ndarray, buf: np.ndarray, pos: int) -> int:
+    """Write the JSON text of ``arr`` at ``buf[pos:]`` (uint8, room for the bound);
+    returns the position after it."""
     lib = _lib()
     shape = (c_long * max(arr.ndim, 1))(*arr.shape)
-    cap = int(lib.nf_json_encode_bound(arr.size, arr.ndim))
-    buf = ctypes.create_string_buffer(cap)
     n = lib.nf_json_encode_f32(
-        arr.ctypes.data_as(c_void_p), shape, arr.ndim, buf, cap
+        arr.ctypes.data_as(c_void_p), shape, arr.ndim,
+        c_void_p(buf.ctypes.data + pos), buf.size - pos,
     )
     if n < 0:
-        buf = ctypes.create_string_buffer(-n + 16)
-        n = lib.nf_json_encode_f32(
-            arr.ctypes.data_as(c_void_p), shape, arr.ndim, buf, -n + 16
-        )
-    return buf.raw[:n]
+        raise ValueError("JSON buffer too small")  # the caller sizes it from the bound
+    return pos + int(n)
+
+
+def _text_bound(arr: np.ndarray) -> int:
+    """Room the text of ``arr`` certainly fits in: 17 bytes per number, 4 per list."""
+    lists, numel = 0, 1
+    for d in arr.shape:
+        lists += numel
+        numel *= d
+    return numel * 17 + lists * 4 + 16
+
+
+def encode_tensor_json(tensor: torch.Tensor) -> bytes:
+    """Nested-list JSON text of ``tensor`` (as fp32; integers keep a ``.0``)."""
+    arr = _as_f32_array(tensor)
+    buf = np.empty(_text_bound(arr), dtype=np.uint8)  # not zero-filled
+    end = _encode_into(arr, buf, 0)
+    return buf[:end].tobytes()
 
 
 def _decode_prefix(text: bytes, pos: int) -> tuple[torch.Tensor, int]:
@@ -105,15 +122,34 @@ def _decode_prefix(text: bytes, pos: int) -> tuple[torch.Tensor, int]:
 
 
 def encode_state_json(state: dict[str, Any]) -> bytes:
-    """``{"name": [[...]], ...}`` for a dict of tensors (or nested lists)."""
-    parts = []
+    """``{"name": [[...]], ...}`` for a dict of tensors (or nested lists): written into one
+    buffer, copied out once."""
+    entries = []
+    room = 2
     for name, value in state.items():
-        if isinstance(value, torch.Tensor):
-            body = encode_tensor_json(value)
+        key = json.dumps(str(name)).encode() + b": "
+        body = _as_f32_array(value) if isinstance(value, torch.Tensor) else json.dumps(value).encode()
+        entries.append((key, body))
+        room += len(key) + 2 + (_text_bound(body) if isinstance(body, np.ndarray) else len(body))
+    buf = np.empty(room, dtype=np.uint8)
+    pos = 0
+
+    def put(raw: bytes) -> None:
+        nonlocal pos
+        buf[pos : pos + len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+        pos += len(raw)
+
+    put(b"{")
+    for i, (key, body) in enumerate(entries):
+        if i:
+            put(b", ")
+        put(key)
+        if isinstance(body, np.ndarray):
+            pos = _encode_into(body, buf, pos)
         else:
-            body = json.dumps(value).encode()
-        parts.append(json.dumps(str(name)).encode() + b": " + body)
-    return b"{" + b", ".join(parts) + b"}"
+            put(body)
+    put(b"}")
+    return buf[:pos].tobytes()
 
 
 def decode_state_json(text: bytes, start: int = 0, stop: int | None = None) -> dict[str, torch.Tensor]:

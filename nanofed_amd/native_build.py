@@ -42,7 +42,7 @@ HIPCC_FLAGS = [
     "-Wno-unused-command-line-argument",
 ]
 
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
 
 
 def _hipcc() -> str:
@@ -114,7 +114,7 @@ def build_host(force: bool = False, jobs: int = 4) -> Path:
             o.unlink()
     objs, changed = _compile_all("g++", HOST_FLAGS, sources, "host", jobs)
     if changed or not HOST_LIB.exists():
-        _produce(HOST_LIB, ["g++", "-shared", *map(str, objs), "-lcrypto"])
+        _produce(HOST_LIB, ["g++", "-shared", *map(str, objs), "-lcrypto", "-pthread"])
     return HOST_LIB
 
 

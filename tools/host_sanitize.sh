@@ -9,6 +9,6 @@ g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -stat
     -fno-sanitize-recover=undefined \
     "$root"/csrc/host/crypto.cpp "$root"/csrc/host/tensor_json.cpp \
     "$root"/csrc/host/philox_cpu.cpp "$root"/csrc/host/tests/selftest.cpp \
-    -lcrypto -o "$out"
+    -lcrypto -pthread -o "$out"
 ASAN_OPTIONS=detect_leaks=1:abort_on_error=0:verify_asan_link_order=0 \
     UBSAN_OPTIONS=print_stacktrace=1 "$out"
