@@ -37,15 +37,37 @@ NF_IX int gemm_tile_index(int id, int total_tiles) {
 }
 
 // ---- MNIST CNN (mnist_cnn.hip) -----------------------------------------------------
-// conv2 forward band image: pixel p (= row * 26 + col) owns 64 bytes (32 channels), its
-// 16-byte chunk `chunk` sits at chunk position chunk ^ ((col >> 1) & 3)
-NF_IX int mnist_fwd_swz(int pixel, int col, int chunk) {
-    return pixel * 64 + ((chunk ^ ((col >> 1) & 3)) << 4);
+// Both convolution images are padded, not swizzled: a fragment address is then one
+// per-lane base plus a compile-time offset (tap row, tap column, k step), so the inner
+// loops compute no addresses at all.
+//
+// conv2 forward band image: 10 rows of 26 pixels, 64 bytes (32 channels) per pixel, rows
+// 1680 bytes apart (26 * 64 + 16).  In 16-byte units a pixel is 4 and a row 105 (odd):
+// with the window-major row order of the MFMA blocks (lane n = position n & 3 of pooling
+// window n >> 2 of a 4 x 8 pixel block) the 16 lanes of a ds_read_b128 group then read
+// 16 different 16-byte slots of the 256-byte bank row.
+constexpr int kMnistFwdPixPitch = 64, kMnistFwdRowPitch = 26 * 64 + 16;
+NF_IX int mnist_fwd_off(int row, int col, int chunk) {
+    return row * kMnistFwdRowPitch + col * kMnistFwdPixPitch + (chunk << 4);
 }
-// conv2 data-gradient patch: 13 x 28 pixels of 128 bytes (64 channels)
+// (dy, dx) of row m of a forward MFMA block inside its 4 x 8 pixel block
+NF_IX int mnist_fwd_block_dy(int m) { return 2 * (m >> 4) + ((m >> 1) & 1); }
+NF_IX int mnist_fwd_block_dx(int m) { return 2 * ((m >> 2) & 3) + (m & 1); }
+// conv2 data-gradient patch: 13 rows of 28 pixels, 144 bytes per pixel (128 of channels
+// + 16), rows 4256 bytes apart (28 * 144 + 224).  In 16-byte units a pixel is 9 and a row
+// 266 = 10 (mod 16), so the pixels of a 32-pixel block - consecutive pixels of the
+// 26-wide image, across row ends - advance by 9 (mod 16) each: any 16 lanes of a read
+// group hit 16 different slots, whatever the tap shift.
 constexpr int kMnistDgPatchRows = 13, kMnistDgPatchCols = 28;
-NF_IX int mnist_dg_swz(int pr, int pc, int part) {
-    return (pr * kMnistDgPatchCols + pc) * 128 + ((part ^ (((pc >> 1) + 5 * pr) & 7)) << 4);
+constexpr int kMnistDgPixPitch = 144, kMnistDgRowPitch = 28 * 144 + 224;
+NF_IX int mnist_dg_off(int pr, int pc, int part) {
+    return pr * kMnistDgRowPitch + pc * kMnistDgPixPitch + (part << 4);
+}
+// the four groups of 16 lanes that a ds_read_b128 serves in one LDS cycle each
+NF_IX int lds_b128_group(int lane) {
+    const int l = lane & 31;
+    const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
+    return g + 2 * (lane >> 5);
 }
 
 // ---- MFMA 32x32x16 accumulator layout (nf_device.h) ----------------------------------

@@ -196,17 +196,17 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
 }
 
 // ---------------------------------------------------------------------------
-constexpr int kFwdLds = 64 * 592;  // filter staging (37888 B) > band image (260 * 64)
+constexpr int kFwdLds = 64 * 592;  // filter staging (37888 B) > band image (10 * 1680)
 
-// LDS image of a band: pixel p (= row * 26 + col) owns 64 bytes; its 16-byte
-// chunk ch is stored at chunk position ch ^ ((col >> 1) & 3).  With the
-// window-major row order of the MFMA blocks every ds_read_b128 lane group then
-// touches 16 distinct 16-byte slots of the 256-byte bank row.
-__device__ __forceinline__ int fwd_swz(int pixel, int col, int chunk) {
-    return nfix::mnist_fwd_swz(pixel, col, chunk);
-}
+// LDS image of a band: 10 rows of 26 pixels, 64 bytes per pixel, rows 1680 bytes apart
+// (nfix::mnist_fwd_off).  No swizzle: with the window-major row order of the MFMA blocks
+// the odd row pitch alone makes every ds_read_b128 lane group conflict-free, and a
+// fragment address is a per-lane base plus a compile-time offset.
+constexpr int kFwdRowPitch = nfix::kMnistFwdRowPitch, kFwdPixPitch = nfix::kMnistFwdPixPitch;
+constexpr int kFwdRowPieces = kFwdRowPitch / 16 - 1;  // 104 pieces of 16 bytes per image row
 
-__global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv2_fwd_kernel(MnistCtx c) {
     if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / c.split, g = blockIdx.y, tid = threadIdx.x;
@@ -237,22 +237,28 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
     const float bias = (c.arena + g * c.arena_stride)[c.off_c2b + nb * 32 + n];
 
     // row m of a 32-pixel block is position q of pooling window wi (m = 4*wi + q)
-    const int wi = n >> 2, q = n & 3;
-    const int dy = 2 * (wi >> 2) + (q >> 1), dx = 2 * (wi & 3) + (q & 1);
+    const int dy = nfix::mnist_fwd_block_dy(n), dx = nfix::mnist_fwd_block_dx(n);
+    // this wave's blocks of a band: rows 4 * mgrp .. + 3, columns 8 * i .. + 7, i = 0, 1, 2
+    const char* const afrag = smem + nfix::mnist_fwd_off(4 * mgrp + dy, dx, h);
 
     const bf16* a1img = c.a1 + (static_cast<long>(g) * c.B + b) * (kA1Pix * kA1C);
-    const long out_img = (static_cast<long>(g) * c.B + b) * kP2Pix;
     const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
     const unsigned long long ctr = c.train ? c.step_counter[g] : 0ull;
     const unsigned long long seed = client_seed(c, g);
     // dropout decisions are 8-bit draws: p is honoured to 1/256
-    const unsigned drop_thr = static_cast<unsigned>(c.p_drop1 * 256.0f + 0.5f);
+    const unsigned drop_thr = c.train ? static_cast<unsigned>(c.p_drop1 * 256.0f + 0.5f) : 0u;
+    // pooled pixel (2 * mgrp, h) of band 0, this lane's channel: every store of the
+    // kernel is this plus a compile-time offset (band, block, window row / column)
+    const long out0 = ((static_cast<long>(g) * c.B + b) * kP2Pix + 2 * mgrp * 12 + h) * kC2 +
+                      nb * 32 + n;
+    bf16* const p2out = c.p2 + out0;
+    uint8_t* const pmout = c.pmask + out0;
 
     // fixed piece -> LDS address of this thread's share of a band (pieces
     // tid + 256 i; only threads 0..15 own a fifth piece)
     const int p4 = min(tid + 1024, 1039);
     const bool has4 = tid + 1024 < 1040;
-#define NF_FWD_DST(p) fwd_swz((p) >> 2, ((p) >> 2) % 26, (p) & 3)
+#define NF_FWD_DST(p) (((p) / kFwdRowPieces) * kFwdRowPitch + ((p) % kFwdRowPieces) * 16)
     const int dst0 = NF_FWD_DST(tid), dst1 = NF_FWD_DST(tid + 256), dst2 = NF_FWD_DST(tid + 512),
               dst3 = NF_FWD_DST(tid + 768), dst4 = NF_FWD_DST(p4);
 #undef NF_FWD_DST
@@ -277,45 +283,44 @@ __global__ void __launch_bounds__(256) conv2_fwd_kernel(MnistCtx c) {
         __syncthreads();
 #undef NF_FWD_ISSUE
 
-        unsigned rnd[4] = {~0u, ~0u, ~0u, ~0u};
+        unsigned rnd[3] = {~0u, ~0u, ~0u};
         if (c.train) {
             const unsigned long long blk =
                 ((static_cast<unsigned long long>(b) * 3 + band) * 2 + mgrp) * 64 + nb * 32 + n;
             const nf::Philox4 r = nf::philox4x32_10(seed, 2 * ctr, blk);
-            rnd[0] = r.v[0]; rnd[1] = r.v[1]; rnd[2] = r.v[2]; rnd[3] = r.v[3];
+            rnd[0] = r.v[0]; rnd[1] = r.v[1]; rnd[2] = r.v[2];
         }
-#pragma unroll 1
+        const int band_off = band * 4 * 12 * kC2;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int mbi = mgrp * 3 + i;
-            const int by = mbi / 3, bx = mbi - by * 3;
-            const int oy = by * 4 + dy, ox = bx * 8 + dx;
-            const unsigned rbits = i == 0 ? rnd[0] : (i == 1 ? rnd[1] : rnd[2]);
             f32x16 acc = {0};
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
                 const int tap = s >> 1, kh = tap / 3, kw = tap - kh * 3;
-                const int col = ox + kw;
                 const bf16x8 A = *reinterpret_cast<const bf16x8*>(
-                    smem + fwd_swz((oy + kh) * 26 + col, col, (s & 1) * 2 + h));
+                    afrag + kh * kFwdRowPitch + (8 * i + kw) * kFwdPixPitch + (s & 1) * 32);
                 acc = mfma32(A, Bf[s], acc);
             }
+            const unsigned rbits = rnd[i];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                float best = acc[4 * rg] + bias;
-                int am = 0;
-#pragma unroll
-                for (int qq = 1; qq < 4; ++qq) {
-                    const float v = acc[4 * rg + qq] + bias;
-                    if (v > best) { best = v; am = qq; }
-                }
-                bool alive = best > 0.f;
-                if (c.train) alive = alive && (((rbits >> (8 * rg)) & 0xFFu) >= drop_thr);
+                // max and arg-max (first of equals) of the window; the bias is common to
+                // the four positions, so it is added to the maximum only
+                const float a0 = acc[4 * rg], a1 = acc[4 * rg + 1], a2 = acc[4 * rg + 2],
+                            a3 = acc[4 * rg + 3];
+                const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                // (flat selects and a bitwise AND: nested ?: and && become branches here)
+                const bool c0 = a0 == mx, c1 = a1 == mx, c2 = a2 == mx;
+                int am = c2 ? 2 : 3;
+                am = c1 ? 1 : am;
+                am = c0 ? 0 : am;
+                const float best = mx + bias;
+                const bool alive = (best > 0.f) & (((rbits >> (8 * rg)) & 0xFFu) >= drop_thr);
                 const float val = alive ? best * keep_scale : 0.f;
-                const int ph = band * 4 + by * 2 + (rg >> 1);
-                const int pw = bx * 4 + 2 * (rg & 1) + h;
-                const long o = (out_img + ph * 12 + pw) * kC2 + nb * 32 + n;
-                c.p2[o] = f2bf(val);
-                c.pmask[o] = static_cast<uint8_t>(am | (alive ? 4 : 0));
+                // pooled pixel (band * 4 + 2 * mgrp + (rg >> 1), 4 * i + 2 * (rg & 1) + h)
+                const int o = band_off + ((rg >> 1) * 12 + 4 * i + 2 * (rg & 1)) * kC2;
+                p2out[o] = f2bf(val);
+                pmout[o] = static_cast<uint8_t>(am + (alive ? 4 : 0));
             }
         }
     }
@@ -695,48 +700,72 @@ fc1_wgrad_kernel(MnistCtx c, int step) {
 // The 2x2 window of one pooled pixel, 8 channels: position q (= 2 * dy + dx)
 // receives the pooled gradient of the channels whose arg-max code is q, zero
 // for the others.  One load of gradient and codes serves all four positions.
+//
+// A 32-bit word holds two channels; which halves survive at position q is a function of
+// their two 2-bit codes, i.e. of 16 cases: a 256-byte table in LDS holds, per case, the
+// four AND masks of q = 0..3, so a word costs one ds_read_b128 and four ANDs instead of
+// a chain of shifts, compares and selects (the expansion used to be half of the VALU
+// instructions of conv2_dgrad).  Any 16 lanes read whole, 16-byte-aligned entries:
+// different entries lie in different banks, equal ones are broadcast.
+constexpr int kPoolLutBytes = 256;
+
+__device__ __forceinline__ void pool_lut_init(char* lut, int tid) {
+    if (tid < 64) {
+        const unsigned entry = tid >> 2, q = tid & 3;
+        const unsigned lo = (entry & 3u) == q ? 0x0000FFFFu : 0u;
+        const unsigned hi = (entry >> 2) == q ? 0xFFFF0000u : 0u;
+        reinterpret_cast<unsigned*>(lut)[tid] = lo | hi;
+    }
+}
+
 struct PoolWindow {
-    unsigned w[4], h0[4], h1[4];  // h*: one-hot of the winning position, low / high channel of a word
-    __device__ __forceinline__ PoolWindow(uint4 v, uint2 m) {
+    unsigned w[4];
+    uint4 mk[4];  // mk[k]: masks of word k for q = 0..3
+    // v: pooled gradient of 8 channels; m: their codes (bits 0-1 arg-max position)
+    __device__ __forceinline__ PoolWindow(uint4 v, uint2 m, const char* lut) {
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        const unsigned mm[2] = {m.x, m.y};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned pair = mm[k >> 1] >> (16 * (k & 1));
-            h0[k] = 1u << (pair & 3u);
-            h1[k] = 1u << ((pair >> 8) & 3u);
-        }
+        // byte offset of the entry of a channel pair: 16 * (code_lo | code_hi << 2)
+        unsigned z0 = (m.x << 4) & 0x30303030u, z1 = (m.y << 4) & 0x30303030u;
+        z0 |= z0 >> 6;
+        z1 |= z1 >> 6;
+        const char* t = static_cast<const char*>(__builtin_assume_aligned(lut, 16));
+        mk[0] = *reinterpret_cast<const uint4*>(t + (z0 & 0xF0u));
+        mk[1] = *reinterpret_cast<const uint4*>(t + ((z0 >> 16) & 0xF0u));
+        mk[2] = *reinterpret_cast<const uint4*>(t + (z1 & 0xF0u));
+        mk[3] = *reinterpret_cast<const uint4*>(t + ((z1 >> 16) & 0xF0u));
     }
     __device__ __forceinline__ uint4 at(int q) const {
         unsigned o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned lo = 0u - ((h0[k] >> q) & 1u), hi = 0u - ((h1[k] >> q) & 1u);
-            o[k] = w[k] & ((lo & 0x0000FFFFu) | (hi & 0xFFFF0000u));
+            const unsigned msk = q == 0 ? mk[k].x : (q == 1 ? mk[k].y : (q == 2 ? mk[k].z : mk[k].w));
+            o[k] = w[k] & msk;
         }
         return make_uint4(o[0], o[1], o[2], o[3]);
     }
 };
 
-constexpr int kDgPatchRows = nfix::kMnistDgPatchRows, kDgPatchCols = nfix::kMnistDgPatchCols;
-constexpr int kDgPatchBytes = kDgPatchRows * kDgPatchCols * 128;  // 46592
+// LDS image of the data-gradient patch (nfix::mnist_dg_off): 13 rows of 28 pixels, 144
+// bytes per pixel, rows 4256 bytes apart - padded, not swizzled, so that the 36 fragment
+// reads of a block are one per-lane base plus compile-time offsets.
+constexpr int kDgPatchRows = nfix::kMnistDgPatchRows;
+constexpr int kDgRowPitch = nfix::kMnistDgRowPitch, kDgPixPitch = nfix::kMnistDgPixPitch;
+constexpr int kDgPatchBytes = kDgPatchRows * kDgRowPitch;         // 55328
 constexpr int kDgPixPad = 704;                                    // 22 blocks of 32
-constexpr int kDgLds = kDgPatchBytes + 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10 * 4;
+// patch | normalised input image + 784 ones | pixel -> image offset | pixel -> ReLU bits |
+// conv1 gradient tiles of the four waves | pooling table
+constexpr int kDgLds = kDgPatchBytes + 2 * 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10 * 4 + kPoolLutBytes;
 
-// 128 bytes per patch pixel (row pr, column pc); chunk position is XOR-ed with
-// ((pc >> 1) + 5 * pr) & 7: conflict-free for 32 linear pixels of a 26-wide
-// image shifted by any tap, including the row wrap inside a block.
-__device__ __forceinline__ int dg_swz(int pr, int pc, int part) {
-    return nfix::mnist_dg_swz(pr, pc, part);
-}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off, int bx, int g) {
     if (client_idle(c, g)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);       // normalised input image
-    int* soff = reinterpret_cast<int*>(xs + 784);                     // a1 pixel -> offset in xs
+    float* xs = reinterpret_cast<float*>(smem + kDgPatchBytes);       // normalised input image, then ones
+    int* soff = reinterpret_cast<int*>(xs + 2 * 784);                 // a1 pixel -> offset in xs
     unsigned* smask = reinterpret_cast<unsigned*>(soff + kDgPixPad);  // a1 pixel -> ReLU bits
     float* red = reinterpret_cast<float*>(smask + kDgPixPad);
+    const char* lut = reinterpret_cast<const char*>(red + 4 * 32 * 10);
     const int b = bx / c.split, tid = threadIdx.x;
     const int chunk0 = c.split == 1 ? 0 : bx - b * c.split;
     const int chunk1 = c.split == 1 ? 3 : chunk0 + 1;
@@ -754,6 +783,7 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
             const int p = tid + i * 256, row = p >> 3, part = p & 7;
             *reinterpret_cast<uint4*>(smem + row * 128 + ((part ^ ((row >> 1) & 7)) << 4)) = wsrc[p];
         }
+        pool_lut_init(const_cast<char*>(lut), tid);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 36; ++ks) {
@@ -774,6 +804,7 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
             xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
             xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
             xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
+            *reinterpret_cast<float4*>(xs + 784 + 4 * tid) = make_float4(1.f, 1.f, 1.f, 1.f);
         }
         const uint32_t* am = c.a1mask + img * kA1Pix;
         for (int p = tid; p < kDgPixPad; p += 256) {
@@ -782,11 +813,10 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
             smask[p] = p < kA1Pix ? am[p] : 0u;
         }
     }
-    // conv1 gradient tile Z[c][t]: t = 0..8 the taps, t = 9 the bias
+    // conv1 gradient tile Z[c][t]: t = 0..8 the taps, t = 9 the bias (its "input" is the
+    // block of ones behind the image); columns t > 9 read the image and are never stored
     f32x16 Z = {0};
-    const int tapoff = n < 9 ? (n / 3) * 28 + (n % 3) : 0;
-    const float xone = n == 9 ? 1.f : 0.f;
-    const bool xtap = n < 9;
+    const int tapoff = n < 9 ? (n / 3) * 28 + (n % 3) : (n == 9 ? 784 : 0);
     const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
     const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
 
@@ -816,15 +846,19 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
             const int py = py_base + prow, px = pcol - 1;
             const bool inside = py >= 0 && py < 12 && px >= 0 && px < 12;
             const int pooled = min(max(py, 0), 11) * 12 + min(max(px, 0), 11);
-            const uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
+            uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
             const uint2 m = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);
-            const PoolWindow win(v, m);
+            if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
+            const PoolWindow win(v, m, lut);
+            // window rows 2 * py and 2 * py + 1 of the image, relative to the patch
+            const int pr = 2 * py - oy_base;
+            char* const dst = smem + nfix::mnist_dg_off(pr, 2 * px + 2, part);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int pr = 2 * py + (q >> 1) - oy_base, pc = 2 * px + (q & 1) + 2;
-                const uint4 o = inside ? win.at(q) : make_uint4(0u, 0u, 0u, 0u);
-                if (it < nitems && pr >= 0 && pr < nrows)
-                    *reinterpret_cast<uint4*>(smem + dg_swz(pr, pc, part)) = o;
+                const int prq = pr + (q >> 1);
+                if (it < nitems && prq >= 0 && prq < nrows)
+                    *reinterpret_cast<uint4*>(dst + (q >> 1) * kDgRowPitch + (q & 1) * kDgPixPitch) =
+                        win.at(q);
             }
         }
         __syncthreads();
@@ -835,13 +869,15 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
             if (mb >= mb0 + nmb) break;  // wave-uniform
             const int p = min(mb * 32 + n, kA1Pix - 1);
             const int y = p / 26, x = p - y * 26;
-            const int pr0 = y - oy_base, pc0 = x + 2;
+            // tap (kh, kw) reads patch pixel (y - oy_base - kh, x + 2 - kw): the address of
+            // tap (2, 2) plus compile-time offsets
+            const char* const afrag = smem + nfix::mnist_dg_off(y - oy_base - 2, x, h);
             f32x16 acc = {0};
 #pragma unroll
             for (int ks = 0; ks < 36; ++ks) {
                 const int tap = ks >> 2, kh = tap / 3, kw = tap - kh * 3;
                 const bf16x8 A = *reinterpret_cast<const bf16x8*>(
-                    smem + dg_swz(pr0 - kh, pc0 - kw, (ks & 3) * 2 + h));
+                    afrag + (2 - kh) * kDgRowPitch + (2 - kw) * kDgPixPitch + (ks & 3) * 32);
                 acc = mfma32(A, Bf[ks], acc);
             }
             // ReLU mask of conv1's output; the masked tile is the A operand
@@ -850,16 +886,23 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
             const int pb = mb * 32 + 4 * h;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 Aa, Bx;
+                unsigned Aw[4];
+                bf16x8 Bx;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int pp = pb + 16 * s + 8 * (j >> 2) + (j & 3);
-                    const unsigned bits = smask[pp];
-                    Aa[j] = f2bf(((bits >> n) & 1u) ? acc[8 * s + j] : 0.f);
-                    const float xv = xs[soff[pp] + tapoff];
-                    Bx[j] = f2bf(xtap ? xv : xone);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j0 = 2 * jj, j1 = j0 + 1;
+                    const int pp0 = pb + 16 * s + 8 * (j0 >> 2) + (j0 & 3), pp1 = pp0 + 1;
+                    // bit n of a pixel's word, spread over a bf16: 0 or 0xFFFF
+                    const int m0 = __builtin_amdgcn_sbfe(static_cast<int>(smask[pp0]), n, 1);
+                    const int m1 = __builtin_amdgcn_sbfe(static_cast<int>(smask[pp1]), n, 1);
+                    const unsigned keep = __builtin_amdgcn_perm(m1, m0, 0x05040100u);
+                    const bf16x2 pair = {f2bf(acc[8 * s + j0]), f2bf(acc[8 * s + j1])};
+                    Aw[jj] = __builtin_bit_cast(unsigned, pair) & keep;
+                    Bx[j0] = f2bf(xs[soff[pp0] + tapoff]);
+                    Bx[j1] = f2bf(xs[soff[pp1] + tapoff]);
                 }
-                Z = mfma32(Aa, Bx, Z);
+                const uint4 Au = make_uint4(Aw[0], Aw[1], Aw[2], Aw[3]);
+                Z = mfma32(__builtin_bit_cast(bf16x8, Au), Bx, Z);
             }
         }
     }
@@ -912,13 +955,14 @@ bwd_pair_kernel(MnistCtx c, int idx_off, int step, int n_dg) {
 constexpr int kWgDaPitch = 192;  // 128 B of channels + 64 B
 constexpr int kWgDaBytes = 192 * kWgDaPitch;  // 36864
 constexpr int kWgA1Bytes = 260 * 64;          // 16640
-constexpr int kWgLds = kWgDaBytes + kWgA1Bytes;
+constexpr int kWgLds = kWgDaBytes + kWgA1Bytes + kPoolLutBytes;
 
 __device__ __forceinline__ void conv2_wgrad_body(const MnistCtx& c, int wg, int g) {
     if (client_idle(c, g)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_da = smem;               // [192 px][64 oc], pitch 192
     char* s_a1 = smem + kWgDaBytes;  // [260 px][32 c], pitch 64
+    char* lut = s_a1 + kWgA1Bytes;   // pooling-window masks (PoolWindow)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const int ocb = wave & 1, tg = wave >> 1;
@@ -954,10 +998,11 @@ __device__ __forceinline__ void conv2_wgrad_body(const MnistCtx& c, int wg, int 
         pa0 = sa1_[tid]; pa1 = sa1_[tid + 384]; pa2 = sa1_[q2];                         \
     }
     NF_WG_ISSUE(0)
+    pool_lut_init(lut, tid);
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
         {
-            const PoolWindow win(pv, pm);
+            const PoolWindow win(pv, pm, lut);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<uint4*>(da_dst + ((q >> 1) * 24 + (q & 1)) * kWgDaPitch) = win.at(q);
@@ -1348,12 +1393,23 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / kHeadRows, c->G), dim3(256), 0, s, *c, idx_off, step); break;
     case 4: hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 128 * kTrPitch128, s, *c); break;
     case 5: hipLaunchKernelGGL(fc1_wgrad_kernel, dim3(kFc1Tiles, c->G), dim3(256), 2 * 64 * kTrPitch128, s, *c, step); break;
-    case 6: hipLaunchKernelGGL(conv2_dgrad_kernel, split_grid, dim3(256), kDgLds, s, *c, idx_off); break;
+    case 6: {
+        static const hipError_t lds_ok = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(conv2_dgrad_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, kDgLds);
+        if (lds_ok != hipSuccess) return -20;
+        hipLaunchKernelGGL(conv2_dgrad_kernel, split_grid, dim3(256), kDgLds, s, *c, idx_off);
+        break;
+    }
     case 7: hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(c->WPC, c->G), dim3(384), kWgLds, s, *c); break;
     case 8: hipLaunchKernelGGL(finalize_kernel<false>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step); break;
     case 13: {
         // conv2_dgrad + fc1_wgrad side by side (plain SGD only)
         if (c->dp_pass != 0) return -12;
+        static const hipError_t lds_ok = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(bwd_pair_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds);
+        if (lds_ok != hipSuccess) return -20;
         const int n_dg = c->B * c->split;
         hipLaunchKernelGGL(bwd_pair_kernel, dim3(n_dg + kFc1Tiles, c->G), dim3(256), kPairLds, s,
                            *c, idx_off, step, n_dg);

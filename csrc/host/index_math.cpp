@@ -7,8 +7,11 @@ extern "C" {
 int nf_ix_gemm_kc_off(int row, int chunk) { return nfix::gemm_kc_off(row, chunk); }
 int nf_ix_gemm_km_off(int rowb, int k, int xb) { return nfix::gemm_km_off(rowb, k, xb); }
 int nf_ix_gemm_tile_index(int id, int total) { return nfix::gemm_tile_index(id, total); }
-int nf_ix_mnist_fwd_swz(int pixel, int col, int chunk) { return nfix::mnist_fwd_swz(pixel, col, chunk); }
-int nf_ix_mnist_dg_swz(int pr, int pc, int part) { return nfix::mnist_dg_swz(pr, pc, part); }
+int nf_ix_mnist_fwd_off(int row, int col, int chunk) { return nfix::mnist_fwd_off(row, col, chunk); }
+int nf_ix_mnist_fwd_block_dy(int m) { return nfix::mnist_fwd_block_dy(m); }
+int nf_ix_mnist_fwd_block_dx(int m) { return nfix::mnist_fwd_block_dx(m); }
+int nf_ix_mnist_dg_off(int pr, int pc, int part) { return nfix::mnist_dg_off(pr, pc, part); }
+int nf_ix_lds_b128_group(int lane) { return nfix::lds_b128_group(lane); }
 int nf_ix_mfma32_acc_row(int reg, int lane) { return nfix::mfma32_acc_row(reg, lane); }
 int nf_ix_conv_patch_source(int H, int W, int logH, int RI, int Cin, int row0, int pp) {
     return nfix::conv_patch_source(H, W, logH, RI, Cin, row0, pp);

@@ -15,7 +15,8 @@ from nanofed_amd import native_build
 def ix():
     native_build.build_host()
     lib = ctypes.CDLL(str(native_build.HOST_LIB))
-    for name in ("gemm_kc_off", "gemm_km_off", "gemm_tile_index", "mnist_fwd_swz", "mnist_dg_swz",
+    for name in ("gemm_kc_off", "gemm_km_off", "gemm_tile_index", "mnist_fwd_off", "mnist_fwd_block_dy", "mnist_fwd_block_dx",
+                 "mnist_dg_off", "lds_b128_group",
                  "mfma32_acc_row", "conv_patch_source", "conv_patch_index", "conv_patch_byte",
                  "conv_patch_frag_byte", "conv_patch_read_cycles", "conv_patch_row_pitch",
                  "conv_patch_band_pitch"):
@@ -60,27 +61,67 @@ def test_every_tile_is_owned_by_exactly_one_workgroup(ix, total):
         assert mine == list(range(mine[0], mine[0] + len(mine)))
 
 
+def _slots_distinct(addresses_by_lane, group_of):
+    """Every ds_read_b128 lane group (16 lanes) touches 16 different 16-byte slots of the
+    256-byte bank row."""
+    groups = {}
+    for lane, addr in addresses_by_lane.items():
+        groups.setdefault(group_of(lane), []).append((addr % 256) // 16)
+    return all(len(s) == 16 and len(set(s)) == 16 for s in groups.values())
+
+
 def test_mnist_forward_band_image(ix):
-    # a band: 10 rows of 26 pixels, 64 bytes each (the kernel stages 260 pixels)
-    offs = np.array([[ix.nf_ix_mnist_fwd_swz(p, p % 26, ch) for ch in range(4)] for p in range(260)])
-    assert offs.min() == 0 and offs.max() == 260 * 64 - 16 and (offs % 16 == 0).all()
-    assert len(np.unique(offs)) == 260 * 4
-    assert ((offs // 64) == np.arange(260)[:, None]).all()
+    # a band: 10 rows of 26 pixels, 64 bytes each, rows 1680 bytes apart
+    offs = np.array([[[ix.nf_ix_mnist_fwd_off(r, c, ch) for ch in range(4)] for c in range(26)]
+                     for r in range(10)])
+    assert offs.min() == 0 and offs.max() == 9 * 1680 + 25 * 64 + 48 and (offs % 16 == 0).all()
+    assert len(np.unique(offs)) == offs.size and offs.max() + 16 <= 64 * 592
+    # the staging pieces (104 per row) and the fragment reads address the same bytes
+    for piece in range(1040):
+        row, col16 = divmod(piece, 104)
+        assert row * 1680 + col16 * 16 == ix.nf_ix_mnist_fwd_off(row, col16 // 4, col16 % 4)
+    # rows of a block: every pooling window (4 consecutive rows) is a 2 x 2 pixel square
+    pos = [(ix.nf_ix_mnist_fwd_block_dy(m), ix.nf_ix_mnist_fwd_block_dx(m)) for m in range(32)]
+    assert sorted(pos) == [(y, x) for y in range(4) for x in range(8)]
+    for w in range(8):
+        ys = {pos[4 * w + q][0] for q in range(4)}
+        xs = {pos[4 * w + q][1] for q in range(4)}
+        assert len(ys) == 2 and len(xs) == 2 and max(ys) - min(ys) == 1 and max(xs) - min(xs) == 1
+    # conflict-free fragment reads for every block position, tap and k half
+    for mgrp in range(2):
+        for i in range(3):
+            for kh in range(3):
+                for kw in range(3):
+                    for half in range(2):
+                        addr = {
+                            lane: ix.nf_ix_mnist_fwd_off(4 * mgrp + pos[lane & 31][0] + kh,
+                                                        8 * i + pos[lane & 31][1] + kw,
+                                                        2 * half + (lane >> 5))
+                            for lane in range(64)
+                        }
+                        assert max(addr.values()) + 16 <= 10 * 1680
+                        assert _slots_distinct(addr, ix.nf_ix_lds_b128_group)
 
 
 def test_mnist_dgrad_patch(ix):
-    offs = np.array([[[ix.nf_ix_mnist_dg_swz(pr, pc, part) for part in range(8)]
+    offs = np.array([[[ix.nf_ix_mnist_dg_off(pr, pc, part) for part in range(8)]
                       for pc in range(28)] for pr in range(13)])
-    assert offs.min() == 0 and offs.max() == 13 * 28 * 128 - 16 and (offs % 16 == 0).all()
+    assert offs.min() == 0 and (offs % 16 == 0).all() and offs.max() + 16 <= 13 * 4256
     assert len(np.unique(offs)) == offs.size
-    pix = np.arange(13)[:, None] * 28 + np.arange(28)[None, :]
-    assert ((offs // 128) == pix[:, :, None]).all()
-    # 8 consecutive pixels of a row read the same part from 8... at least 4 distinct 16-byte
-    # slots per 4 pixels (two pixels share a pair index by construction)
-    for pr in range(13):
-        for part in range(8):
-            slots = [(ix.nf_ix_mnist_dg_swz(pr, pc, part) % 128) // 16 for pc in range(0, 16, 2)]
-            assert len(set(slots)) == 8
+    # blocks of 32 consecutive pixels of the 26-wide image, shifted by any tap: one LDS
+    # cycle per lane group, across the ends of image rows as well
+    for mb in range(22):
+        for kh in range(3):
+            for kw in range(3):
+                for ks in range(4):
+                    addr = {}
+                    for lane in range(64):
+                        p = min(mb * 32 + (lane & 31), 675)
+                        y, x = divmod(p, 26)
+                        addr[lane] = ix.nf_ix_mnist_dg_off(y + 2 - kh, x + 2 - kw,
+                                                           2 * ks + (lane >> 5))
+                    if mb * 32 + 31 <= 675:  # (the clamped tail block repeats one pixel)
+                        assert _slots_distinct(addr, ix.nf_ix_lds_b128_group)
 
 
 def test_accumulator_rows_cover_the_tile_once(ix):
