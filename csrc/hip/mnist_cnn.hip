@@ -90,7 +90,7 @@ struct MnistCtx {
     uint32_t* a1mask;       // [G][B][676] bit c = conv1 output (pixel, c) > 0
     float* conv1_part;      // [G][B*split][320]
     float* conv2_part;      // [G][WPC][18432]
-    float* c2b_part;        // [G][72][64]
+    float* c2b_part;        // [G][144][64] conv2.bias partial sums: one row per pooled pixel, over the batch
     float* head_part;       // [G][B/8][1440]
     float* metrics;         // [G][4] loss sum, accuracy sum, batches, -
     float* eval_out;        // [G][B/8][2] loss sum, correct count per workgroup of the last step (eval mode)
@@ -134,13 +134,28 @@ __device__ __forceinline__ unsigned long long client_seed(const MnistCtx& c, int
 }
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off) {
+// conv1 as a matrix product on the fp32 matrix cores: D[channel][pixel] = W[channel][k] *
+// X[k][pixel] with k = 9 taps + 1 bias row (X = 1), five v_mfma_f32_32x32x2_f32 per block
+// of 32 pixels - exact fp32 products, as the scalar loop this replaces (72 FMAs per pixel
+// and channel group, most of the kernel's instructions).  With the channels as rows a lane
+// ends up with four runs of 4 consecutive channels of ONE pixel; a half-swap between the
+// lanes of a pixel (v_permlane32_swap) turns them into two 16-byte stores.
+//
+// ReLU mask word of a pixel: the bit of channel c is conv1_mask_bit(c) - the order in which
+// the accumulator registers of the two lane halves hold the channels.
+__device__ __forceinline__ int conv1_mask_bit(int c) {
+    return (c & 3) + 4 * (c >> 3) + 16 * ((c >> 2) & 1);
+}
+
+// (at least two waves per SIMD: with a budget of 256 registers the compiler keeps the
+// matrix results in VGPRs, where the epilogue reads them without v_accvgpr_read copies)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+conv1_fwd_kernel(MnistCtx c, int idx_off) {
     if (client_idle(c, blockIdx.y)) return;
     const int b = blockIdx.x / c.conv1_split, part = blockIdx.x % c.conv1_split;
     const int g = blockIdx.y, tid = threadIdx.x;
-    __shared__ float xs[784];
-    __shared__ float ws[288];
-    __shared__ float bs[32];
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    __shared__ float xs[784 + 4];  // the image, then the 1.0 that multiplies the bias
     const int row = c.idx[g * c.idx_stride + idx_off + b];
     const uint8_t* img = c.images + static_cast<long>(row) * 784;
     if (tid < 196) {
@@ -150,48 +165,70 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(MnistCtx c, int idx_off)
         xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
         xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
         xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
+    } else if (tid == 196) {
+        xs[784] = 1.0f;
     }
+    // A operand: row = channel n, k = 2 s + h.  k = 0..8 the taps, k = 9 the bias.
     const float* wa = c.arena + g * c.arena_stride;
-    for (int i = tid; i < 288; i += 256) ws[i] = wa[c.off_c1w + i];
-    if (tid < 32) bs[tid] = wa[c.off_c1b + tid];
+    float wk[5];
+    int xoff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int k = 2 * s + h;
+        wk[s] = k < 9 ? wa[c.off_c1w + n * 9 + k] : wa[c.off_c1b + n];
+        xoff[s] = (k / 3) * 28 + k % 3;  // (k = 9 is replaced below)
+    }
     __syncthreads();
 
     bf16* out = c.a1 + (static_cast<long>(g) * c.B + b) * (kA1Pix * kA1C);
-    // a thread always serves the same group of 8 channels (256 % 4 == 0):
-    // their 72 weights and 8 biases stay in registers
-    const int cg = tid & 3;
-    float wr[8][9], br[8];
+    uint32_t* mask_out = c.a1mask + (static_cast<long>(g) * c.B + b) * kA1Pix;
+    constexpr int kBlocks = (kA1Pix + 31) / 32;  // 22, the last one holds 4 pixels
+    const int blk0 = part * kBlocks / c.conv1_split, blk1 = (part + 1) * kBlocks / c.conv1_split;
+    for (int blk = blk0 + wave; blk < blk1; blk += 4) {
+        const int p = blk * 32 + n;
+        const int pc = min(p, kA1Pix - 1);
+        const int y = pc / 26, x = pc - y * 26;
+        const int pb = y * 28 + x;
+        f32x16 acc = {0};
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-        br[cc] = bs[cg * 8 + cc];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wr[cc][t] = ws[(cg * 8 + cc) * 9 + t];
-    }
-    const int kTasks = kA1Pix * 4 / c.conv1_split;  // a multiple of 4 for 1, 2, 4
-    for (int task = part * kTasks + tid; task < (part + 1) * kTasks; task += 256) {
-        const int px = task >> 2;
-        const int y = px / 26, x = px - y * 26;
-        float xv[9];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xs[(y + kh) * 28 + x + kw];
-        bf16x8 o;
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[s], xs[pb + xoff[s]], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[4], xs[h ? 784 : pb + 58], acc, 0, 0, 0);
+        // register r: channel (r & 3) + 8 * (r >> 2) + 4 * h of pixel p
         unsigned bits = 0;
+        unsigned pk[8];
+        float neg[16];  // 0 - acc: its sign bit says acc > 0, and max(-neg, 0) is the ReLU
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            float acc = br[cc];
+        for (int r = 0; r < 16; ++r) neg[r] = 0.f - acc[r];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc = fmaf(wr[cc][t], xv[t], acc);
-            o[cc] = f2bf(fmaxf(acc, 0.f));
-            bits |= (acc > 0.f ? 1u : 0u) << cc;
+        for (int r = 15; r >= 0; --r)  // bit r <- (acc[r] > 0)
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(neg[r]), 31);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // (the maximum is taken of an arithmetic result, which needs no canonicalising
+            // instruction in front of it; of the matrix result itself it would)
+            const bf16x2 two = {f2bf(fmaxf(-neg[2 * i], 0.f)), f2bf(fmaxf(-neg[2 * i + 1], 0.f))};
+            pk[i] = __builtin_bit_cast(unsigned, two);
         }
-        *reinterpret_cast<bf16x8*>(out + px * kA1C + cg * 8) = o;
-        // the four lanes of a pixel are adjacent: merge their 8-bit groups
-        unsigned m = bits << (8 * cg);
-        m |= __shfl_xor(m, 1, 64);
-        m |= __shfl_xor(m, 2, 64);
-        if (cg == 0) c.a1mask[(static_cast<long>(g) * c.B + b) * kA1Pix + px] = m;
+        // pk[2 q'], pk[2 q' + 1]: channels 8 q' + 4 h .. + 3.  Swap the upper half's q' = 0
+        // (2) with the lower half's q' = 1 (3): h = 0 then holds channels 0..7 (16..23),
+        // h = 1 channels 8..15 (24..31) of the pixel.
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(pk[4 * pair + w], pk[4 * pair + 2 + w],
+                                                                 false, false);
+                pk[4 * pair + w] = sw[0];
+                pk[4 * pair + 2 + w] = sw[1];
+            }
+        const unsigned other = __shfl_xor(bits, 32, 64);
+        if (p < kA1Pix) {
+            uint4* dst = reinterpret_cast<uint4*>(out + p * kA1C + 8 * h);
+            dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            dst[2] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            if (h == 0) mask_out[p] = bits | (other << 16);
+        }
     }
 }
 
@@ -535,6 +572,12 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
 // ---------------------------------------------------------------------------
 constexpr int kTrPitch128 = 320;  // 256 B of data + 64 B: 4 consecutive k rows hit distinct banks
 
+// The product is formed transposed, D[channel][batch row] = W1 tile^T * dh1^T (the same two
+// fragments as for D[batch row][channel], operands exchanged), so that a lane ends up with
+// runs of 4 consecutive channels of ONE pooled pixel of one sample; after a half-swap
+// between the two lanes of a sample (v_permlane32_swap) it owns 8 consecutive channels:
+// 8-byte loads of the arg-max / alive codes and 16-byte stores of the gradient instead of
+// one byte and two bytes per lane and instruction.
 __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
     if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [128 j][128 k'] pitch 320
@@ -553,49 +596,77 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             Af[mb][ks] = *reinterpret_cast<const bf16x8*>(dh + (mb * 32 + n) * 128 + ks * 16);
-    // the alive bits this lane will need in the epilogue: fetched now, used after the GEMM
-    const int pp = tile * 2 + (wave >> 1), ch = (wave & 1) * 32 + n;
-    uint8_t mk[2][16];
+    // the codes this lane will need in the epilogue: fetched now, used after the GEMM.
+    // Sample mb * 32 + n, pooled pixel pp, channels cbase + 16 * pair + 8 * h .. + 7.
+    const int pp = tile * 2 + (wave >> 1), cbase = (wave & 1) * 32;
+    const long o0 = ((static_cast<long>(g) * c.B + n) * kP2Pix + pp) * kC2 + cbase + 8 * h;
+    uint2 mk[2][2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = mb * 32 + acc_row(r, lane);
-            mk[mb][r] = c.pmask[((static_cast<long>(g) * c.B + b) * kP2Pix + pp) * kC2 + ch];
-        }
+        for (int pair = 0; pair < 2; ++pair)
+            mk[mb][pair] = *reinterpret_cast<const uint2*>(
+                c.pmask + o0 + static_cast<long>(mb) * 32 * kP2Pix * kC2 + 16 * pair);
     __syncthreads();
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc[2] = {{0}, {0}};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 Bfr = load_tr_frag(smem, kTrPitch128, ks * 16, wave * 32, lane);
-        acc0 = mfma32(Af[0][ks], Bfr, acc0);
-        acc1 = mfma32(Af[1][ks], Bfr, acc1);
+        const bf16x8 Wfr = load_tr_frag(smem, kTrPitch128, ks * 16, wave * 32, lane);
+        acc[0] = mfma32(Wfr, Af[0][ks], acc[0]);
+        acc[1] = mfma32(Wfr, Af[1][ks], acc[1]);
     }
-    // dropout + ReLU backward on the pooled gradient; conv2 bias gradient
+    // dropout + ReLU backward on the pooled gradient.  conv2's bias gradient is the sum of
+    // these (bf16-rounded) values over samples and pixels: every wave leaves its
+    // [64 samples][32 channels] tile in LDS as well and sums its columns with four MFMAs
+    // against a matrix of ones.
     const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
-    float bsum = 0.f;
+    __syncthreads();  // the weight tile is no longer needed: its space takes the tiles
+    constexpr int kSumPitch = 80;  // 64 B of channels + 16: conflict-free transposed reads
+    char* const tile_w = smem + wave * (64 * kSumPitch);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
+        // register r: channel cbase + (r & 3) + 8 * (r >> 2) + 4 * h
+        unsigned pk[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = mb * 32 + acc_row(r, lane);
-            const long o = ((static_cast<long>(g) * c.B + b) * kP2Pix + pp) * kC2 + ch;
-            const uint8_t m = mk[mb][r];
-            const bf16 vb = f2bf((mb == 0 ? acc0[r] : acc1[r]) * ((m & 4) ? keep_scale : 0.f));
-            c.dp2[o] = vb;
-            bsum += bf2f(vb);
+        for (int i = 0; i < 8; ++i) {
+            const bf16x2 two = {f2bf(acc[mb][2 * i] * keep_scale), f2bf(acc[mb][2 * i + 1] * keep_scale)};
+            pk[i] = __builtin_bit_cast(unsigned, two);
+        }
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(pk[4 * pair + ww], pk[4 * pair + 2 + ww],
+                                                                 false, false);
+                pk[4 * pair + ww] = sw[0];
+                pk[4 * pair + 2 + ww] = sw[1];
+            }
+            // pk[4 pair .. + 3]: channels cbase + 16 pair + 8 h + 0..7; byte e of the codes
+            // belongs to channel e, its bit 2 says "alive"
+            const unsigned mw[2] = {mk[mb][pair].x, mk[mb][pair].y};
+            unsigned out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lo = __builtin_amdgcn_sbfe(static_cast<int>(mw[j >> 1]), 16 * (j & 1) + 2, 1);
+                const int hi = __builtin_amdgcn_sbfe(static_cast<int>(mw[j >> 1]), 16 * (j & 1) + 10, 1);
+                out[j] = pk[4 * pair + j] & __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            }
+            const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<uint4*>(c.dp2 + o0 + static_cast<long>(mb) * 32 * kP2Pix * kC2 + 16 * pair) = o4;
+            *reinterpret_cast<uint4*>(tile_w + (mb * 32 + n) * kSumPitch + (16 * pair + 8 * h) * 2) = o4;
         }
     }
-    bsum += __shfl_xor(bsum, 32, 64);
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    if (h == 0) red[wave * 32 + n] = bsum;
-    __syncthreads();
-    if (tid < 64) {
-        const int cb = tid >> 5, nn = tid & 31;
-        c.c2b_part[(static_cast<long>(g) * kFc1Tiles + tile) * 64 + tid] =
-            red[cb * 32 + nn] + red[(2 + cb) * 32 + nn];
-    }
+    // column sums: D[any row][channel] = sum over the 64 samples (k) of tile[k][channel]
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = f2bf(1.0f);
+    f32x16 colsum = {0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        colsum = mfma32(ones, load_tr_frag(tile_w, kSumPitch, ks * 16, 0, lane), colsum);
+    // register 0 of the lower lane half is row 0: channel cbase + n of pooled pixel pp
+    if (h == 0)
+        c.c2b_part[(static_cast<long>(g) * 2 * kFc1Tiles + pp) * 64 + cbase + n] = colsum[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -756,8 +827,6 @@ constexpr int kDgPixPad = 704;                                    // 22 blocks o
 // conv1 gradient tiles of the four waves | pooling table
 constexpr int kDgLds = kDgPatchBytes + 2 * 784 * 4 + kDgPixPad * 4 * 2 + 4 * 32 * 10 * 4 + kPoolLutBytes;
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off, int bx, int g) {
     if (client_idle(c, g)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -817,6 +886,7 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
     // block of ones behind the image); columns t > 9 read the image and are never stored
     f32x16 Z = {0};
     const int tapoff = n < 9 ? (n / 3) * 28 + (n % 3) : (n == 9 ? 784 : 0);
+    const int mbit = conv1_mask_bit(n);  // this lane's channel in the ReLU mask words
     const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
     const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
 
@@ -893,8 +963,8 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
                     const int j0 = 2 * jj, j1 = j0 + 1;
                     const int pp0 = pb + 16 * s + 8 * (j0 >> 2) + (j0 & 3), pp1 = pp0 + 1;
                     // bit n of a pixel's word, spread over a bf16: 0 or 0xFFFF
-                    const int m0 = __builtin_amdgcn_sbfe(static_cast<int>(smask[pp0]), n, 1);
-                    const int m1 = __builtin_amdgcn_sbfe(static_cast<int>(smask[pp1]), n, 1);
+                    const int m0 = __builtin_amdgcn_sbfe(static_cast<int>(smask[pp0]), mbit, 1);
+                    const int m1 = __builtin_amdgcn_sbfe(static_cast<int>(smask[pp1]), mbit, 1);
                     const unsigned keep = __builtin_amdgcn_perm(m1, m0, 0x05040100u);
                     const bf16x2 pair = {f2bf(acc[8 * s + j0]), f2bf(acc[8 * s + j1])};
                     Aw[jj] = __builtin_bit_cast(unsigned, pair) & keep;
@@ -1215,9 +1285,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
         w2t_at = (e2 - oc * 288) * 64 + oc;
     } else if (e < kConv1Part + kConv2Part + 64) {
         const int e2 = e - kConv1Part - kConv2Part;
-        count = kFc1Tiles;
+        count = 2 * kFc1Tiles;
         stride = 64;
-        src = c.c2b_part + static_cast<long>(g) * kFc1Tiles * 64 + e2;
+        src = c.c2b_part + static_cast<long>(g) * count * 64 + e2;
         if (dp_weighted) {
             count = c.B;
             src = c.dp_c2b + static_cast<long>(g) * c.B * 64 + e2;

@@ -63,7 +63,19 @@ class EngineConfig:
     # native GPT-2 trainer: concurrent client steps ("lanes", at most 2; see the
     # note in GPT2NativeTrainer.__init__ before raising this from 1)
     gpt2_lanes: int = 1
-    reduce_algo: str = "auto"  # auto | allreduce | rs_ag
+    # FedAvg reduce over the ranks: "ordered" adds the client rows in client order on
+    # every rank's slice (all-to-all of row slices + all-gather; the global model is then
+    # bit-identical for any number of ranks), "allreduce" / "rs_ag" add per-rank partial
+    # sums with the library's all-reduce / reduce-scatter + all-gather (order up to the
+    # library).  "auto": ordered for arenas below 32 MB (where either is latency-bound),
+    # rs_ag above.
+    reduce_algo: str = "auto"  # auto | ordered | allreduce | rs_ag
+    # True: local training does not depend on how many clients share a GPU either (the
+    # native MNIST kernels keep ONE workgroup geometry instead of choosing it from the
+    # number of clients on the GPU), so that together with the ordered reduce a run gives
+    # the same bits on 1, 2, 4 or 8 GPUs - the mode in which a multi-GPU run can be
+    # checked against a single-GPU one.  Costs speed where few clients share a GPU.
+    placement_invariant: bool = False
     drop_last: bool = False
     # native MNIST kernels: conv2 workgroups per image (1 or 3); 0 = choose from
     # the number of clients on the GPU

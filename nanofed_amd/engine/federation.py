@@ -300,7 +300,14 @@ class FederatedEngine:
         K, W = cfg.num_clients, self.comm.world_size
         f32 = dict(dtype=torch.float32, device=self.device)
         self._K = K
-        self._partial = torch.zeros(self.layout.numel, **f32)
+        # the reduced model, in a buffer long enough for the sliced collectives to work
+        # on in place (whole slices of a multiple of 64 elements per rank)
+        self._partial_full = torch.zeros(self.comm.padded_numel(self.layout.numel), **f32)
+        self._partial = self._partial_full[: self.layout.numel]
+        self._ordered_send: torch.Tensor | None = None
+        self._ordered_shard: torch.Tensor | None = None
+        if cfg.reduce_algo not in ("auto", "ordered", "allreduce", "rs_ag"):
+            raise DeviceError(f"unknown reduce_algo {cfg.reduce_algo!r}")
         # per-client records of this rank + one control row [failed flag, ...]
         self._local_records = torch.zeros(self.max_local + 1, METRIC_COLUMNS, **f32)
         self._records = torch.zeros(K, METRIC_COLUMNS, **f32)
@@ -771,14 +778,66 @@ class FederatedEngine:
         if cfg.secure_agg == "pairwise":
             self._secure_reduce(records, lo, G)
         else:
-            ops.weighted_sum(self.pool.rows(), self._weights[lo : lo + G], out=self._partial)
-            comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
+            self._reduce_rows(self._weights, lo, G)
         # 7. quorum select (device-side; the old model survives a failed round)
         ops.select_copy(self.global_arena.data, self._partial, self._flags)
         pack = self._host_pack
         pack[: K * M].copy_(records.reshape(-1))
         pack[K * M : K * M + 4].copy_(self._flags)
         pack[K * M + 4 :].copy_(self._control)
+
+    def _reduce_algo(self) -> str:
+        algo = self.cfg.reduce_algo
+        if algo == "auto":
+            from nanofed_amd.parallel.comm import RS_AG_THRESHOLD_BYTES
+
+            small = self.layout.numel * 4 < RS_AG_THRESHOLD_BYTES
+            algo = "ordered" if small else "rs_ag"
+        return algo
+
+    def _reduce_rows(self, weights: torch.Tensor, lo: int, G: int) -> None:
+        """``self._partial = sum_k weights[k] * row_k`` over the K client rows of all
+        ranks; ``weights`` is the device vector of all K weights, this rank's rows are
+        clients ``lo .. lo + G - 1``.
+
+        *ordered*: every rank receives slice ``rank`` of every client row, adds the K
+        slices in client order - the very chain of fused multiply-adds that one process
+        runs over its K rows, so the sum has the same bits for any number of ranks - and
+        the reduced slices are gathered.  Rows with weight 0 are never read.
+        Otherwise: fused weighted sum of the local rows, then the library's all-reduce."""
+        comm = self.comm
+        algo = self._reduce_algo()
+        if comm.world_size == 1 or algo != "ordered":
+            ops.weighted_sum(self.pool.rows(), weights[lo : lo + G], out=self._partial)
+            if comm.world_size > 1:
+                comm.allreduce_sum(self._partial_full, algo=algo)
+            return
+        W, R, n = comm.world_size, self.max_local, self.layout.numel
+        per = comm.shard_numel(n)
+        if self._ordered_send is None:
+            self._ordered_send = torch.zeros(W, R, per, dtype=torch.float32, device=self.device)
+            self._ordered_shard = torch.zeros(per, dtype=torch.float32, device=self.device)
+        send = self._ordered_send
+        # block s of `send` = slice s of my rows (rows beyond G and the tail of the last
+        # slice stay zero and carry weight 0 / are cut off)
+        rows = self.pool.data  # [G, n]
+        whole = n // per  # slices that lie completely inside a row
+        if whole:
+            send[:whole, :G].copy_(rows[:, : whole * per].view(G, whole, per).transpose(0, 1))
+        if whole < W and n > whole * per:
+            send[whole, :G, : n - whole * per].copy_(rows[:, whole * per :])
+        recv = comm.exchange_row_shards(send)  # [W, R, per]: slice `rank` of rank w's rows
+        sources, index = [], []
+        first = 0
+        for w, count in enumerate(self._rank_counts):
+            for i in range(count):
+                sources.append(recv[w, i])
+                index.append(first + i)
+            first += count
+        # client order = rank-major order of the block placement, so `index` is 0..K-1
+        assert index == list(range(self._K))
+        ops.weighted_sum(sources, weights, out=self._ordered_shard)
+        comm.allgather_shards(self._partial_full, self._ordered_shard)
 
     def _secure_reduce(self, records: torch.Tensor, lo: int, G: int) -> None:
         """FedAvg under pairwise masking (reference capability: the share sums of
@@ -801,8 +860,7 @@ class FederatedEngine:
                 prescale=self._shares_host[cid], offset=offset,
             )
         present = (records[:, M_VALID] > 0).to(torch.float32)
-        ops.weighted_sum(self.pool.rows(), present[lo : lo + G], out=self._partial)
-        comm.allreduce_sum(self._partial, algo=cfg.reduce_algo)
+        self._reduce_rows(present, lo, G)
         ops.pairwise_repair_(self._partial, present, self._secure_seeds, scale, offset=offset)
         mass = (present * self._shares).sum().clamp(min=1e-30)
         self._partial.div_(mass)

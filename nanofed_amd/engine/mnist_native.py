@@ -234,15 +234,20 @@ class NativeBuffers:
             split, wpc, conv1_split = 1, CONV2_WG_PER_CLIENT, 1
         if cfg is not None and cfg.conv_split in (1, 3) and dp is None:
             split = cfg.conv_split
+        # one geometry for every client count: the partial sums of the convolution
+        # gradients are then associated the same way however the clients are placed
+        invariant = cfg is not None and cfg.placement_invariant and dp is None
+        if invariant:
+            split, wpc, conv1_split = 1, 64, 1
         # tuning override: NANOFED_MNIST_GEOMETRY="split,wpc,conv1_split"
         geometry = os.environ.get("NANOFED_MNIST_GEOMETRY")
-        if geometry and dp is None:
+        if geometry and dp is None and not (cfg is not None and cfg.placement_invariant):
             split, wpc, conv1_split = (int(v) for v in geometry.split(","))
         self.conv2_part = z(G, wpc, 18432)
         self.dp_normsq = z(G, B, 4, name="dp_normsq")
         self.dp_rowscale = z(G, B, name="dp_rowscale")
         self.dp_c2b = z(G, B, 64, name="dp_c2b")
-        self.c2b_part = z(G, 72, 64, name="c2b_part")
+        self.c2b_part = z(G, 144, 64, name="c2b_part")
         self.head_part = z(G, B // 8, 1440, name="head_part")
         self.metrics = z(G, 4, name="metrics")
         self.eval_out = z(G, B // 8, 2)
@@ -293,6 +298,8 @@ class NativeBuffers:
         # NANOFED_MNIST_TRIPLE=0|1 overrides (measurements).
         triple = os.environ.get("NANOFED_MNIST_TRIPLE")
         c.bwd_triple = int(triple == "1") if triple in ("0", "1") else int(total <= 1)
+        if invariant:
+            c.bwd_triple = 0
         c.ntotal = self.ntotal.data_ptr() if (train and (micro > 1 or cfg is not None
                                                and cfg.batch_size < BATCH)) else 0
         c.dp_normsq, c.dp_rowscale = self.dp_normsq.data_ptr(), self.dp_rowscale.data_ptr()

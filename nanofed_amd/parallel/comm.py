@@ -14,9 +14,19 @@ same logical traffic is three collectives over flat arenas:
 xGMI is point-to-point (7 links per GPU), so a ring all-reduce of a large
 arena is bound by one link.  ``allreduce_sum`` therefore switches by size:
 small arenas (latency-bound) use a single ``all_reduce``; large arenas use
-``reduce_scatter`` + ``all_gather`` on a padded buffer, which lets RCCL drive
-all peers at once and lets the caller fuse work on the 1/world shard between
-the two phases (``shard_hook``).
+``reduce_scatter`` + ``all_gather``, which lets RCCL drive all peers at once.
+The buffer handed in should be ``padded_numel`` long (the engine allocates it
+so), then neither phase copies.
+
+Both of these leave the order of the additions to the library, so the bits of
+the result depend on the number of ranks.  ``exchange_row_shards`` +
+``allgather_shards`` are the transport of the *ordered* reduce: every rank
+receives slice ``rank`` of EVERY client row (one all-to-all), adds the rows in
+client order with the same kernel a single process uses, and the reduced
+slices are gathered - the same traffic as reduce-scatter + all-gather for one
+client per rank, and a result that is bit-identical for 1, 2, ... ranks
+(reference: the server adds the updates in one fixed loop,
+nanofed/server/aggregator/fedavg.py:56-63).
 
 ``gloo`` only ever sees CPU tensors: device tensors are staged through host
 memory with synchronous copies.
@@ -64,7 +74,7 @@ class Communicator:
         self._owns_group = owns_group
         # a world of one skips every collective unless this is set
         self._single = world_size == 1 and not (force_collectives and group is not None)
-        self._pad: dict[int, torch.Tensor] = {}
+        self._pad: dict[str, torch.Tensor] = {}
 
     # -- construction -----------------------------------------------------
     @classmethod
@@ -113,30 +123,52 @@ class Communicator:
             owns = True
         return cls(rank, world, local_rank, backend, device, dist.group.WORLD, owns, force)
 
-    def close(self) -> None:
-        """Leave the job: the ranks meet once more (so that none tears its connections down
-        while another still uses them), then the group is destroyed."""
+    CLOSE_WAIT_S = 10.0
+
+    def close(self, failed: bool = False) -> None:
+        """Leave the job: the ranks meet once more (so that none tears its connections
+        down while another still uses them), then the group is destroyed.  The meeting
+        is a count in the rendezvous store, polled for at most ``CLOSE_WAIT_S`` seconds:
+        it launches nothing on the device and cannot hang on a peer that is gone
+        (a collective barrier would sit there until the group's own time-out).
+        ``failed=True`` - the job is ending because of an error - skips it."""
         if self._owns_group and dist.is_initialized():
-            try:
-                self.barrier()
-            except Exception:  # noqa: BLE001 - a peer that is gone already cannot be waited for
-                pass
+            if not failed and self.world_size > 1:
+                self._meet("nanofed/close")
             dist.destroy_process_group()
             self._owns_group = False
 
+    def _meet(self, key: str) -> bool:
+        """True when every rank arrived at ``key`` within ``CLOSE_WAIT_S``."""
+        import time
+
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            store.add(key, 1)
+            deadline = time.monotonic() + self.CLOSE_WAIT_S
+            while time.monotonic() < deadline:
+                if store.add(key, 0) >= self.world_size:
+                    return True
+                time.sleep(0.005)
+        except Exception:  # noqa: BLE001 - the store lives on rank 0, which may be gone
+            pass
+        return False
+
     def finish(self, code: int = 0) -> None:
-        """End a multi-process job's process: ``close()``, flush the standard streams and
-        leave without running the interpreter's and the libraries' exit handlers.  The
-        collective libraries keep helper threads of their own, and their tear-down at
-        interpreter exit has been seen to abort a rank that had finished all of its work
-        (``terminate called without an active exception``, about one three-rank gloo job
-        in fifteen); a launcher reads that as a failed job.  With one process this is a
+        """End a multi-process job's process; the LAST call of a worker.  ``close()``,
+        then everything that exit handlers would have flushed is flushed here (logging
+        handlers, the standard streams) and the process leaves without running the
+        interpreter's and the libraries' tear-down: the collective libraries keep helper
+        threads of their own, and a rank that has finished all of its work must not be
+        turned into a failed job by their exit-time races.  With one process this is a
         plain return - there is nothing to race with."""
         multi = self.world_size > 1
-        self.close()
+        self.close(failed=code != 0)
         if multi:
+            import logging
             import sys
 
+            logging.shutdown()
             sys.stdout.flush()
             sys.stderr.flush()
             os._exit(code)
@@ -171,56 +203,85 @@ class Communicator:
             self._run(flat, lambda t: dist.broadcast(t, src=src, group=self.group))
         return flat
 
-    def allreduce_sum(
-        self,
-        flat: torch.Tensor,
-        algo: str = "auto",
-        shard_hook: Callable[[torch.Tensor, int], None] | None = None,
-    ) -> torch.Tensor:
-        """In-place sum over ranks.  ``algo``: ``auto`` | ``allreduce`` |
-        ``rs_ag``.  ``shard_hook(shard, start)`` runs on this rank's reduced
-        1/world slice between reduce-scatter and all-gather (``rs_ag`` only)."""
+    def shard_numel(self, numel: int) -> int:
+        """Elements of one rank's slice of a ``numel``-long arena (a multiple of 64)."""
+        per = (numel + self.world_size - 1) // self.world_size
+        return (per + 63) // 64 * 64
+
+    def padded_numel(self, numel: int) -> int:
+        """Length to allocate for a buffer of ``numel`` elements so that the sliced
+        collectives work on it in place."""
+        return self.shard_numel(numel) * self.world_size
+
+    def allreduce_sum(self, flat: torch.Tensor, algo: str = "auto") -> torch.Tensor:
+        """In-place sum over ranks.  ``algo``: ``auto`` | ``allreduce`` | ``rs_ag``."""
         if algo not in ("auto", "allreduce", "rs_ag"):
             raise DeviceError(f"unknown all-reduce algorithm {algo!r}")
         if self._single:
-            if shard_hook is not None:
-                shard_hook(flat, 0)
             return flat
         if algo == "auto":
             big = flat.numel() * flat.element_size() >= RS_AG_THRESHOLD_BYTES
-            algo = "rs_ag" if (big or shard_hook is not None) else "allreduce"
+            algo = "rs_ag" if big else "allreduce"
         if algo == "allreduce":
             self._run(
                 flat, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             )
             return flat
-        self._run(flat, lambda t: self._rs_ag(t, shard_hook))
+        self._run(flat, self._rs_ag)
         return flat
 
-    def _rs_ag(
-        self, t: torch.Tensor, shard_hook: Callable[[torch.Tensor, int], None] | None
-    ) -> None:
-        w = self.world_size
+    def _scratch(self, key: str, numel: int, like: torch.Tensor) -> torch.Tensor:
+        buf = self._pad.get(key)
+        if buf is None or buf.numel() != numel or buf.device != like.device or buf.dtype != like.dtype:
+            buf = torch.zeros(numel, dtype=like.dtype, device=like.device)
+            self._pad[key] = buf
+        return buf
+
+    def _rs_ag(self, t: torch.Tensor) -> None:
         n = t.numel()
-        per = (n + w - 1) // w
-        per = (per + 63) // 64 * 64
-        padded = per * w
+        per = self.shard_numel(n)
+        padded = per * self.world_size
         if padded == n:
-            buf = t
+            buf = t  # the usual case: the caller allocated padded_numel elements
         else:
-            buf = self._pad.get(padded)
-            if buf is None or buf.device != t.device or buf.dtype != t.dtype:
-                buf = torch.zeros(padded, dtype=t.dtype, device=t.device)
-                self._pad[padded] = buf
+            buf = self._scratch("rs_ag", padded, t)
             buf[:n].copy_(t)
             buf[n:].zero_()
-        shard = torch.empty(per, dtype=t.dtype, device=t.device)
+        shard = self._scratch("rs_ag_shard", per, t)
         dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
-        if shard_hook is not None:
-            shard_hook(shard, self.rank * per)
         dist.all_gather_into_tensor(buf, shard, group=self.group)
         if buf is not t:
             t.copy_(buf[:n])
+
+    # -- transport of the ordered reduce ------------------------------------
+    def exchange_row_shards(self, send: torch.Tensor) -> torch.Tensor:
+        """All-to-all of row slices.  ``send``: ``[world, R, per]`` - block ``s`` holds
+        slice ``s`` of this rank's R rows.  Returns ``[world, R, per]`` whose block ``w``
+        holds slice ``rank`` of rank w's rows."""
+        if send.dim() != 3 or send.shape[0] != self.world_size or not send.is_contiguous():
+            raise DeviceError("exchange_row_shards expects a contiguous [world, rows, per] tensor")
+        if self._single:
+            return send
+        staged = self._host_staged(send)
+        src = send.detach().to("cpu") if staged else send
+        out = torch.empty_like(src)
+        dist.all_to_all_single(out, src, group=self.group)
+        return out.to(send.device) if staged else out
+
+    def allgather_shards(self, full: torch.Tensor, shard: torch.Tensor) -> torch.Tensor:
+        """``full[w * per : (w + 1) * per] = rank w's shard`` on every rank, in place."""
+        if full.numel() != shard.numel() * self.world_size:
+            raise DeviceError("allgather_shards: the output must hold one shard per rank")
+        if self._single:
+            full.copy_(shard)
+            return full
+        if self._host_staged(full):
+            host = torch.empty(full.numel(), dtype=full.dtype)
+            dist.all_gather_into_tensor(host, shard.detach().to("cpu"), group=self.group)
+            full.copy_(host)
+        else:
+            dist.all_gather_into_tensor(full, shard.contiguous(), group=self.group)
+        return full
 
     def allgather(self, local: torch.Tensor) -> torch.Tensor:
         """``[world, *local.shape]`` stack of every rank's tensor."""

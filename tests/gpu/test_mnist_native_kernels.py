@@ -187,6 +187,7 @@ def test_fc1_dgrad_pool_backward(env):
         want = alive.float() * dp2
         got = buf.dp2[k].float().view(B, 12, 12, 64)
         torch.testing.assert_close(got, want, rtol=1e-2, atol=1e-6)
+        # conv2.bias: column sums of the stored values (MFMA against ones inside fc1_dgrad)
         gv = eng.pool[k].grad_views()
         ref_b = got.sum((0, 1, 2))
         torch.testing.assert_close(gv["conv2.bias"], ref_b, rtol=1e-3,
@@ -200,8 +201,12 @@ def test_conv2_dgrad_with_conv1_wgrad(env):
     for k in range(G):
         da2 = _da2_from_pooled(buf, k).permute(0, 3, 1, 2)
         a1 = buf.a1[k].float().view(B, 26, 26, 32).permute(0, 3, 1, 2)
+        # ReLU mask words: the bit of channel c is (c & 3) + 4 (c >> 3) + 16 ((c >> 2) & 1),
+        # the order in which conv1's accumulator registers hold the channels
+        ch = torch.arange(32, device="cuda")
+        bit = (ch & 3) + 4 * (ch >> 3) + 16 * ((ch >> 2) & 1)
         assert torch.equal(
-            (buf.a1mask[k].view(B, 676, 1) >> torch.arange(32, device="cuda")) & 1,
+            (buf.a1mask[k].view(B, 676, 1) >> bit) & 1,
             (buf.a1[k].view(B, 676, 32) > 0).int(),
         )
         da1 = F.conv_transpose2d(da2, bf(env["sds"][k]["conv2.weight"])) * (a1 > 0)

@@ -35,11 +35,23 @@ def _env(**extra):
     return env
 
 
-_TRANSPORT_TROUBLE = ("Address already in use", "Connection refused", "Connection reset",
-                      "connect() timed out", "Socket Timeout", "Broken pipe",
-                      "failed to connect", "DistNetworkError", "DistStoreError",
-                      # a library helper thread that aborts a finished process at exit
-                      "terminate called without an active exception")
+# what a job prints when its ranks never got to meet (the store port was taken meanwhile,
+# the machine was too busy to answer in time): a rendezvous failure, before any collective
+_RENDEZVOUS_TROUBLE = ("Address already in use", "Connection refused", "connect() timed out",
+                       "Socket Timeout", "failed to connect", "DistNetworkError",
+                       "DistStoreError")
+
+
+def _never_met(stderr: str) -> bool:
+    return any(t in stderr for t in _RENDEZVOUS_TROUBLE) and "round" not in stderr.lower()
+
+
+def _note_retry(what: str, stderr: str) -> None:
+    import warnings
+
+    warnings.warn(f"{what}: rendezvous failed, job started once more: {stderr[-300:]!r}",
+                  stacklevel=2)
+
 
 BENCH_ARGS = ["--cpu", "--steps", "2", "--warmup", "1", "--model", "mnist_mlp",
               "--samples-per-client", "64", "--batch-size", "32", "--backend", "torch",
@@ -55,8 +67,9 @@ def _bench(nproc: int, dump: str) -> dict:
                f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
-    if proc.returncode != 0 and nproc > 1 and any(t in proc.stderr for t in _TRANSPORT_TROUBLE):
+    if proc.returncode != 0 and nproc > 1 and _never_met(proc.stderr):
         # the ranks did not get to meet (busy machine, port taken meanwhile): once more
+        _note_retry(f"bench.py on {nproc} ranks", proc.stderr)
         cmd[cmd.index("--master-port") + 1] = str(_free_port())
         proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert proc.returncode == 0, proc.stderr[-3000:]
@@ -79,8 +92,12 @@ def test_bench_under_the_launcher_prints_one_json_line_and_the_same_model(tmp_pa
     assert multi["config"]["parallelism"] == f"fed8/gpu{nproc}"
     a = torch.load(tmp_path / "one.pt", weights_only=True)
     b = torch.load(tmp_path / "many.pt", weights_only=True)
-    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
-    assert multi["final_train_loss"] == pytest.approx(single["final_train_loss"], rel=1e-4)
+    # the ordered reduce adds the client rows in one order whatever the number of ranks
+    assert torch.equal(a, b)
+    assert multi["model_sha256"] == single["model_sha256"]
+    assert multi["ranks_seen"] == nproc and len(multi["devices"]) == nproc
+    assert sum(multi["clients_per_rank"]) == 8
+    assert multi["final_train_loss"] == pytest.approx(single["final_train_loss"], rel=1e-6)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
@@ -152,30 +169,53 @@ def _run_ok(tmp_path, nproc, cfg, timeout=300, **kw):
     """Launch a job that is expected to end with status 0 on every rank.  The ranks meet
     over local TCP (store + gloo pairs) on a port that was free a few seconds earlier; on a
     busy machine that meeting can fail for reasons that have nothing to do with the code
-    under test, so a job that died of a transport error is started once more."""
+    under test, so a job whose ranks never met is started once more (with a warning in the
+    test report); a job that fails after its ranks have met fails the test."""
     for attempt in (0, 1):
         procs, out = _launch(tmp_path, nproc, cfg, **kw)
         codes = _wait(procs, timeout)
         errs = [p.stderr.read() for p in procs]
         if codes == [0] * nproc:
             return out
-        if attempt == 0 and any(t in e for e in errs for t in _TRANSPORT_TROUBLE):
+        if attempt == 0 and any(_never_met(e) for e in errs):
+            _note_retry(f"{nproc}-rank job", " | ".join(errs))
             continue
         raise AssertionError(f"exit codes {codes}: {[e[-1500:] for e in errs]}")
     raise AssertionError("unreachable")
 
 
-def test_eight_clients_on_three_ranks_equal_the_single_process_run(tmp_path):
-    out = _run_ok(tmp_path, 3, BASE_CFG)
+@pytest.fixture(scope="module")
+def single_process_run(tmp_path_factory):
+    """Three rounds in ONE worker process, started like the ranks of the multi-process
+    jobs (same script, same environment: the host BLAS with one thread, so that local
+    training itself computes the same bits)."""
+    out = _run_ok(tmp_path_factory.mktemp("single"), 1, BASE_CFG, rounds=3)
+    return torch.load(out, weights_only=False)
+
+
+@pytest.mark.parametrize("nproc", [2, 3, 4, pytest.param(8, marks=pytest.mark.slow)])
+def test_any_number_of_ranks_gives_the_bits_of_the_single_process_run(tmp_path, nproc,
+                                                                       single_process_run):
+    """8 clients on 2, 3 (uneven placement), 4 and 8 ranks, three rounds: the ordered
+    reduce adds the client rows in client order on every rank, so the global model is
+    bit-identical to the one-process run (reference: one fixed-order loop on the server,
+    nanofed/server/aggregator/fedavg.py:56-63)."""
+    single = single_process_run
+    out = _run_ok(tmp_path, nproc, BASE_CFG, rounds=3)
     dist = torch.load(out, weights_only=False)
-    single = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
-    reps = single.run(2)
-    torch.testing.assert_close(dist["flat"], single.global_arena.data, rtol=1e-5, atol=1e-6)
-    assert dist["weights"] == pytest.approx([c["weight"] for c in reps[-1].client_metrics])
-    assert dist["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-4)
+    assert torch.equal(dist["flat"], single["flat"])
+    assert dist["weights"] == single["weights"] and dist["loss"] == single["loss"]
+    assert dist["rounds"] == [0, 1, 2]
 
 
-def test_a_failure_on_one_rank_only_is_agreed_on_and_recovered_by_all(tmp_path):
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_library_reduces_agree_with_the_ordered_one_to_rounding(tmp_path, algo, single_process_run):
+    out = _run_ok(tmp_path, 3, dict(BASE_CFG, reduce_algo=algo), rounds=3)
+    dist = torch.load(out, weights_only=False)
+    torch.testing.assert_close(dist["flat"], single_process_run["flat"], rtol=1e-5, atol=1e-6)
+
+
+def test_a_failure_on_one_rank_only_is_agreed_on_and_recovered_by_all(tmp_path, single_process_run):
     cfg = dict(BASE_CFG, checkpoint_rounds=True)
     # only rank 1 raises, in the middle of round 1; rank 0 finishes its training
     faults = dict(fail={1: "HIP error: injected on one rank"}, fail_ranks={1})
@@ -183,9 +223,7 @@ def test_a_failure_on_one_rank_only_is_agreed_on_and_recovered_by_all(tmp_path):
     dist = torch.load(out, weights_only=False)
     assert dist["recoveries"] == 1
     assert dist["rounds"] == [0, 1, 2] and dist["status"] == ["COMPLETED"] * 3
-    clean = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
-    clean.run(3)
-    torch.testing.assert_close(dist["flat"], clean.global_arena.data, rtol=1e-5, atol=1e-6)
+    assert torch.equal(dist["flat"], single_process_run["flat"])
 
 
 def test_a_failure_on_one_rank_without_checkpoints_ends_every_rank(tmp_path):
@@ -198,7 +236,7 @@ def test_a_failure_on_one_rank_without_checkpoints_ends_every_rank(tmp_path):
     assert "RoundFailure" in errs[1] and "rank(s) [0]" in errs[1]
 
 
-def test_a_stalled_rank_ends_the_job_within_the_timeout_and_resume_continues(tmp_path):
+def test_a_stalled_rank_ends_the_job_within_the_timeout_and_resume_continues(tmp_path, single_process_run):
     base = tmp_path / "run"
     cfg = dict(BASE_CFG, round_timeout_s=6.0, enforce_round_timeout=True, first_round_grace_s=60.0)
     # rank 1 hangs for two minutes inside round 1; round 0 completes and is saved
@@ -216,6 +254,4 @@ def test_a_stalled_rank_ends_the_job_within_the_timeout_and_resume_continues(tmp
     out = _run_ok(tmp_path, 2, BASE_CFG, rounds=2, base=str(base), resume=True, name="again")
     again = torch.load(out, weights_only=False)
     assert again["rounds"] == [1, 2] and again["status"] == ["COMPLETED"] * 2
-    clean = FederatedEngine(EngineConfig(**BASE_CFG), comm=Communicator())
-    clean.run(3)
-    torch.testing.assert_close(again["flat"], clean.global_arena.data, rtol=1e-5, atol=1e-6)
+    assert torch.equal(again["flat"], single_process_run["flat"])
