@@ -54,6 +54,65 @@ def _restore_stdout(saved_fd: int) -> None:
     os.dup2(saved_fd, 1)
 
 
+def _sha256(flat: torch.Tensor) -> str:
+    import hashlib
+
+    return hashlib.sha256(flat.contiguous().numpy().tobytes()).hexdigest()
+
+
+def _mean_phases(reports: list) -> dict:
+    sums: dict[str, float] = {}
+    counts: dict[str, int] = {}
+    for rep in reports:
+        for name, ms in (rep.phases_ms or {}).items():
+            sums[name] = sums.get(name, 0.0) + float(ms)
+            counts[name] = counts.get(name, 0) + 1
+    return {name: round(sums[name] / counts[name], 4) for name in sorted(sums)}
+
+
+def _who_ran(comm, engine) -> dict:
+    """Gathered from the ranks through the engine's own transport: one row per rank with
+    (1, device index, PCI bus id) - the sum of the ones is the number of ranks that really
+    took part in a collective."""
+    idx, bus = -1, -1
+    if comm.device.type == "cuda":
+        idx = comm.device.index or 0
+        props = torch.cuda.get_device_properties(idx)
+        bus = int(getattr(props, "pci_bus_id", -1))
+    mine = torch.tensor([1.0, float(idx), float(bus)], dtype=torch.float32, device=comm.device)
+    rows = comm.allgather(mine).cpu()
+    return {
+        "ranks_seen": int(rows[:, 0].sum().item()),
+        "devices": [{"rank": r, "device": int(rows[r, 1]), "pci_bus": int(rows[r, 2])}
+                    for r in range(rows.shape[0])],
+        "clients_per_rank": list(engine._rank_counts),
+        "reduce_algo": engine._reduce_algo() if comm.collective else "local",
+    }
+
+
+def _invariance_check(comm, args) -> dict | None:
+    """Two rounds of a small placement-invariant job (ordered reduce, one kernel geometry);
+    returns the hash of its global model.  Every rank takes part; rank 0 reports."""
+    from nanofed_amd.engine import EngineConfig, FederatedEngine
+
+    if args.clients < comm.world_size:
+        return None
+    cfg = EngineConfig(
+        model=args.model, dataset=args.dataset, num_clients=args.clients, local_epochs=1,
+        batch_size=args.batch_size, learning_rate=args.lr, samples_per_client=512,
+        dtype=args.dtype, backend=args.backend, eval_samples=64, graph_capture=not args.no_graph,
+        reduce_algo="ordered", placement_invariant=True, phase_timing=False,
+    )
+    eng = FederatedEngine(cfg, comm=comm)
+    try:
+        reps = eng.run(2)
+        flat = eng.global_arena.data.detach().cpu()
+        return {"rounds": 2, "samples_per_client": 512, "sha256": _sha256(flat),
+                "train_loss": reps[-1].agg_metrics["loss"]}
+    finally:
+        eng.close()
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +138,13 @@ def main() -> int:
     ap.add_argument("--eval-samples", type=int, default=10000)
     ap.add_argument("--dump-model", default=None,
                     help="rank 0 saves the final global model (flat fp32 tensor) to this file")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="how many times the block of --steps rounds is timed (the value is the median block)")
+    ap.add_argument("--invariant", action="store_true",
+                    help="placement-invariant training (one kernel geometry for any number of clients "
+                         "per GPU): model_sha256 is then the same for every --gpus")
+    ap.add_argument("--no-invariance-check", action="store_true",
+                    help="skip the short placement-invariant run whose hash goes into the record")
     args = ap.parse_args()
 
     from nanofed_amd.engine import EngineConfig, FederatedEngine
@@ -118,6 +184,7 @@ def main() -> int:
         graph_capture=not args.no_graph,
         eval_samples=args.eval_samples,
         prefetch_rounds=not args.no_prefetch,
+        placement_invariant=args.invariant,
     )
     scratch = None
     if not args.no_persist and comm.is_root:
@@ -147,18 +214,32 @@ def main() -> int:
     # it out of the cyclic collector's scans, whose full passes take 50-60 ms here
     gc.collect()
     gc.freeze()
-    elapsed, reports = timed(args.steps)
+    # the block of --steps rounds is timed --repeats times (same work each time); the value
+    # is the median block, the others show the spread of the machine
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        blocks.append(timed(args.steps))
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    elapsed, reports = blocks[order[len(order) // 2]]
+    block_rates = [args.steps / b[0] for b in blocks]
     final = engine.evaluate()
-    dump = engine.global_arena.data.detach().cpu().clone() if args.dump_model else None
+    flat_host = engine.global_arena.data.detach().cpu().clone()
+    dump = flat_host if args.dump_model else None
+    model_sha256 = _sha256(flat_host)
+    phases = _mean_phases([rep for _, reps in blocks for rep in reps])
+    who = _who_ran(comm, engine)
 
     # the same loop without the per-round files (what the writer thread costs)
     bare = None
     if scratch is not None or (not args.no_persist and comm.world_size > 1):
         engine.disable_persistence()
         bare, _ = timed(min(args.steps, 10))
+    check = None
+    if not args.no_invariance_check:
+        check = _invariance_check(comm, args)
     if comm.is_root:
         rounds_per_s = args.steps / elapsed
-        last = reports[-1] if reports else None
+        last = blocks[-1][1][-1] if blocks[-1][1] else None  # the last round that ran with files
         line = {
             "metric": f"federated rounds/sec (MNIST-CNN FedAvg, {args.clients} clients)",
             "value": rounds_per_s,
@@ -175,6 +256,25 @@ def main() -> int:
             "persistence": "off" if args.no_persist else
             "model version (.pt + JSON) and metrics JSON per round, writer thread, flushed in the timed region",
             "rounds_per_s_no_persistence": (min(args.steps, 10) / bare) if bare else None,
+            # every timed block of --steps rounds, in the order they ran
+            "block_rounds_per_s": [round(r, 3) for r in block_rates],
+            "block_min_max": [round(min(block_rates), 3), round(max(block_rates), 3)],
+            # what ran: ranks that took part in a collective, their devices, their clients
+            "ranks_seen": who["ranks_seen"],
+            "devices": who["devices"],
+            "clients_per_rank": who["clients_per_rank"],
+            "reduce_algo": who["reduce_algo"],
+            # mean milliseconds per phase of the timed rounds (device events)
+            "phases_ms": phases,
+            # SHA-256 of the global model (fp32 arena) after warm-up + all timed blocks; it
+            # does not depend on --gpus when training is placement-invariant (--invariant,
+            # or a trainer that is so by construction: the PyTorch ones)
+            "model_sha256": model_sha256,
+            "placement_invariant": bool(args.invariant),
+            # a short run (8 clients, 2 rounds) in placement-invariant mode: the same hash
+            # for every --gpus says that local training and the reduce of THIS build on
+            # THIS machine do not depend on the number of ranks
+            "invariance_check": check,
             "stream_set": (last.trainer_info or None) if last else None,
             "final_test_accuracy": final.get("accuracy"),
             "final_train_accuracy": last.agg_metrics["accuracy"] if last else None,

@@ -705,7 +705,7 @@ class FederatedEngine:
     # steps 3-7
     def _tail(self, local: torch.Tensor | None, failed: bool, eager: bool) -> None:
         graphable = (
-            self.cfg.tail_graph and self.device.type == "cuda" and self.comm.world_size == 1
+            self.cfg.tail_graph and self.device.type == "cuda" and not self.comm.collective
             and not eager and local is not None
         )
         if graphable:
@@ -748,7 +748,7 @@ class FederatedEngine:
             if failed:
                 rec[self.max_local, 0] = 1.0
             # 4. gather the per-client records (+ control rows)
-            if comm.world_size == 1:
+            if not comm.collective:
                 records = rec[:K]
                 self._control.copy_(rec[self.max_local, :1])
             else:
@@ -807,9 +807,9 @@ class FederatedEngine:
         Otherwise: fused weighted sum of the local rows, then the library's all-reduce."""
         comm = self.comm
         algo = self._reduce_algo()
-        if comm.world_size == 1 or algo != "ordered":
+        if not comm.collective or algo != "ordered":
             ops.weighted_sum(self.pool.rows(), weights[lo : lo + G], out=self._partial)
-            if comm.world_size > 1:
+            if comm.collective:
                 comm.allreduce_sum(self._partial_full, algo=algo)
             return
         W, R, n = comm.world_size, self.max_local, self.layout.numel

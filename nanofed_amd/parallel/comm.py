@@ -178,6 +178,12 @@ class Communicator:
     def is_root(self) -> bool:
         return self.rank == 0
 
+    @property
+    def collective(self) -> bool:
+        """True when the collectives really go through a process group (several ranks, or
+        a one-rank group forced for a rehearsal); False when they are the identity."""
+        return not self._single
+
     def _host_staged(self, t: torch.Tensor) -> bool:
         return self.backend == "gloo" and t.device.type != "cpu"
 
