@@ -5,7 +5,7 @@
 //  step: nanofed/trainer/base.py:141-159) for the G simulated clients that share
 // one GPU, all of them in every launch (blockIdx.y = client).
 //
-// One optimisation step is nine launches, none of which synchronises with the
+// One optimisation step is six to eight launches, none of which synchronises with the
 // host; dropout offsets come from a device-side step counter, batch rows from
 // a device index table, so a whole epoch can be recorded in one hipGraph.
 //
@@ -355,6 +355,184 @@ conv2_fwd_kernel(MnistCtx c) {
                 const bool alive = (best > 0.f) & (((rbits >> (8 * rg)) & 0xFFu) >= drop_thr);
                 const float val = alive ? best * keep_scale : 0.f;
                 // pooled pixel (band * 4 + 2 * mgrp + (rg >> 1), 4 * i + 2 * (rg & 1) + h)
+                const int o = band_off + ((rg >> 1) * 12 + 4 * i + 2 * (rg & 1)) * kC2;
+                p2out[o] = f2bf(val);
+                pmout[o] = static_cast<uint8_t>(am + (alive ? 4 : 0));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv1 and conv2 forward in ONE launch.  Both are per image: the workgroup that owns an
+// image (or one band of it) computes conv1's output for its rows on the fp32 matrix cores
+// (conv1_fwd_kernel's scheme) straight into the LDS image that conv2's MFMA loop reads
+// (conv2_fwd_kernel's scheme, all rows resident, so no staging and no barriers between
+// bands), and writes it to memory only for the backward pass.  One launch, one dependent
+// kernel boundary and one 5.5 MB round trip per client and step less than the two
+// kernels; results are bit-identical to theirs.
+constexpr int kFusedXs = 784 + 4;
+constexpr int kFusedImgBytes = 26 * kFwdRowPitch;  // 43680
+constexpr int kFusedLds = kFusedImgBytes + kFusedXs * 4;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv12_fwd_kernel(MnistCtx c, int idx_off) {
+    if (client_idle(c, blockIdx.y)) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem + kFusedImgBytes);
+    const int b = blockIdx.x / c.split, g = blockIdx.y, tid = threadIdx.x;
+    const int band0 = c.split == 1 ? 0 : blockIdx.x - b * c.split;
+    const int band1 = c.split == 1 ? 3 : band0 + 1;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nb = wave & 1, mgrp = wave >> 1;
+    const int n = lane & 31, h = lane >> 5;
+    const long img = static_cast<long>(g) * c.B + b;
+
+    // input image (its loads are the longest dependent chain of the kernel: first)
+    {
+        const int row = c.idx[g * c.idx_stride + idx_off + b];
+        const uint8_t* im = c.images + static_cast<long>(row) * 784;
+        if (tid < 196) {
+            const uchar4 v = reinterpret_cast<const uchar4*>(im)[tid];
+            const float k = 1.0f / 255.0f;
+            xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
+            xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
+            xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
+            xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
+        } else if (tid == 196) {
+            xs[784] = 1.0f;
+        }
+    }
+    // conv2's stationary operand through the (still unused) image area, as in conv2_fwd
+    bf16x8 Bf[18];
+    {
+        const uint4* wsrc =
+            reinterpret_cast<const uint4*>(c.shadow + g * c.shadow_stride + c.off_c2w);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int p = tid + i * 256, row = p / 36, part = p - row * 36;
+            *reinterpret_cast<uint4*>(smem + row * 592 + part * 16) = wsrc[p];
+        }
+    }
+    // conv1's A operand: row = channel n, k = 2 s + h (k = 9: the bias)
+    const float* wa = c.arena + g * c.arena_stride;
+    float wk[5];
+    int xoff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int k = 2 * s + h;
+        wk[s] = k < 9 ? wa[c.off_c1w + n * 9 + k] : wa[c.off_c1b + n];
+        xoff[s] = (k / 3) * 28 + k % 3;
+    }
+    const float bias = wa[c.off_c2b + nb * 32 + n];
+    __syncthreads();
+    {
+        const char* wrow = smem + (nb * 32 + n) * 592 + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) Bf[s] = *reinterpret_cast<const bf16x8*>(wrow + s * 32);
+    }
+    __syncthreads();  // the filter bank is in registers: the area becomes the image
+
+    // ---- conv1 for image rows row0 .. row0 + nrows - 1 (the bands' rows plus two)
+    const int row0 = band0 * 8, nrows = (band1 - band0) * 8 + 2;
+    const int own_rows = band1 == 3 ? nrows : nrows - 2;  // rows another band's workgroup does not write
+    const int npix = nrows * 26;
+    bf16* a1out = c.a1 + img * (kA1Pix * kA1C);
+    uint32_t* mask_out = c.a1mask + img * kA1Pix;
+    for (int blk = wave; blk * 32 < npix; blk += 4) {
+        const int p = blk * 32 + n;
+        const int pc = min(p, npix - 1);
+        const int yl = pc / 26, x = pc - yl * 26;
+        const int pb = (row0 + yl) * 28 + x;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[s], xs[pb + xoff[s]], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[4], xs[h ? 784 : pb + 58], acc, 0, 0, 0);
+        unsigned bits = 0;
+        unsigned pk[8];
+        float neg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) neg[r] = 0.f - acc[r];
+#pragma unroll
+        for (int r = 15; r >= 0; --r)
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(neg[r]), 31);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x2 two = {f2bf(fmaxf(-neg[2 * i], 0.f)), f2bf(fmaxf(-neg[2 * i + 1], 0.f))};
+            pk[i] = __builtin_bit_cast(unsigned, two);
+        }
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(pk[4 * pair + w], pk[4 * pair + 2 + w],
+                                                                 false, false);
+                pk[4 * pair + w] = sw[0];
+                pk[4 * pair + 2 + w] = sw[1];
+            }
+        const unsigned other = __shfl_xor(bits, 32, 64);
+        if (p < npix) {
+            const uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            const uint4 hi = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            // channels 8 h .. + 7 and 16 + 8 h .. + 7: chunks h and 2 + h of the pixel
+            char* ldst = smem + nfix::mnist_fwd_off(yl, x, h);
+            *reinterpret_cast<uint4*>(ldst) = lo;
+            *reinterpret_cast<uint4*>(ldst + 32) = hi;
+            if (yl < own_rows) {
+                const int gp = (row0 + yl) * 26 + x;
+                uint4* dst = reinterpret_cast<uint4*>(a1out + gp * kA1C + 8 * h);
+                dst[0] = lo;
+                dst[2] = hi;
+                if (h == 0) mask_out[gp] = bits | (other << 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 over the resident rows
+    const int dy = nfix::mnist_fwd_block_dy(n), dx = nfix::mnist_fwd_block_dx(n);
+    const char* const afrag0 = smem + nfix::mnist_fwd_off(4 * mgrp + dy, dx, h);
+    const float keep_scale = c.train ? 1.0f / (1.0f - c.p_drop1) : 1.0f;
+    const unsigned long long ctr = c.train ? c.step_counter[g] : 0ull;
+    const unsigned long long seed = client_seed(c, g);
+    const unsigned drop_thr = c.train ? static_cast<unsigned>(c.p_drop1 * 256.0f + 0.5f) : 0u;
+    const long out0 = (img * kP2Pix + 2 * mgrp * 12 + h) * kC2 + nb * 32 + n;
+    bf16* const p2out = c.p2 + out0;
+    uint8_t* const pmout = c.pmask + out0;
+    for (int band = band0; band < band1; ++band) {
+        unsigned rnd[3] = {~0u, ~0u, ~0u};
+        if (c.train) {
+            const unsigned long long blk =
+                ((static_cast<unsigned long long>(b) * 3 + band) * 2 + mgrp) * 64 + nb * 32 + n;
+            const nf::Philox4 r = nf::philox4x32_10(seed, 2 * ctr, blk);
+            rnd[0] = r.v[0]; rnd[1] = r.v[1]; rnd[2] = r.v[2];
+        }
+        const char* const afrag = afrag0 + (band - band0) * 8 * kFwdRowPitch;
+        const int band_off = band * 4 * 12 * kC2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                const int tap = s >> 1, kh = tap / 3, kw = tap - kh * 3;
+                const bf16x8 A = *reinterpret_cast<const bf16x8*>(
+                    afrag + kh * kFwdRowPitch + (8 * i + kw) * kFwdPixPitch + (s & 1) * 32);
+                acc = mfma32(A, Bf[s], acc);
+            }
+            const unsigned rbits = rnd[i];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float a0 = acc[4 * rg], a1 = acc[4 * rg + 1], a2 = acc[4 * rg + 2],
+                            a3 = acc[4 * rg + 3];
+                const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                const bool c0 = a0 == mx, c1 = a1 == mx, c2 = a2 == mx;
+                int am = c2 ? 2 : 3;
+                am = c1 ? 1 : am;
+                am = c0 ? 0 : am;
+                const float best = mx + bias;
+                const bool alive = (best > 0.f) & (((rbits >> (8 * rg)) & 0xFFu) >= drop_thr);
+                const float val = alive ? best * keep_scale : 0.f;
                 const int o = band_off + ((rg >> 1) * 12 + 4 * i + 2 * (rg & 1)) * kC2;
                 p2out[o] = f2bf(val);
                 pmout[o] = static_cast<uint8_t>(am + (alive ? 4 : 0));
@@ -1440,7 +1618,8 @@ int nf_mnist_ctx_size() { return static_cast<int>(sizeof(MnistCtx)); }
 //        6 conv2_dgrad, 7 conv2_wgrad, 8 finalize, 9 sgd_pack, 10 pack only,
 //        11 dp_scale, 12 finalize + SGD of everything but fc1.weight (fuse_sgd only),
 //        13 conv2_dgrad + fc1_wgrad in one launch, 14 advance the step counters,
-//        15 sgd_pack without advancing the counters
+//        15 sgd_pack without advancing the counters,
+//        16 conv2_dgrad + fc1_wgrad + conv2_wgrad in one launch, 17 conv1 + conv2 forward in one launch
 int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStream_t s) {
     const int rc = check_ctx(c);
     if (rc) return rc;
@@ -1452,6 +1631,7 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
     switch (stage) {
     case 0: hipLaunchKernelGGL(conv1_fwd_kernel, dim3(c->B * c->conv1_split, c->G), dim3(256), 0, s, *c, idx_off); break;
     case 1: hipLaunchKernelGGL(conv2_fwd_kernel, split_grid, dim3(256), kFwdLds, s, *c); break;
+    case 17: hipLaunchKernelGGL(conv12_fwd_kernel, split_grid, dim3(256), kFusedLds, s, *c, idx_off); break;
     case 2: {
         static const hipError_t lds_ok = hipFuncSetAttribute(
             reinterpret_cast<const void*>(fc1_fwd_kernel),
@@ -1528,8 +1708,8 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
             // them, or all three when the caller says the chip has room (one client on
             // the GPU: 14.5 -> 13.8 ms per round; with 8 clients in four chains the
             // triple costs 3 %)
-            static const int pair_seq[] = {0, 1, 2, 3, 4, 13, 7, 12};
-            static const int triple_seq[] = {0, 1, 2, 3, 4, 16, 12, -1};
+            static const int pair_seq[] = {17, 2, 3, 4, 13, 7, 12, -1};
+            static const int triple_seq[] = {17, 2, 3, 4, 16, 12, -1, -1};
             const int* few = c->bwd_triple ? triple_seq : pair_seq;
             for (int i = 0; i < 8 && few[i] >= 0; ++i) {
                 const int stage = few[i];
@@ -1539,15 +1719,18 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
             return 0;
         }
         // with fc1.weight updated inside fc1_wgrad, one launch finishes the step
-        const int last = c->fuse_sgd ? 7 : 9;
-        for (int stage = 0; stage <= last; ++stage) {
-            const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
+        static const int fused_seq[] = {17, 2, 3, 4, 5, 6, 7, 12};
+        static const int plain_seq[] = {17, 2, 3, 4, 5, 6, 7, 8, 9};
+        const int* seq = c->fuse_sgd ? fused_seq : plain_seq;
+        const int count = c->fuse_sgd ? 8 : 9;
+        for (int i = 0; i < count; ++i) {
+            const int rc = nf_mnist_stage(c, seq[i], idx_off, step, s);
             if (rc) return rc;
         }
-        return c->fuse_sgd ? nf_mnist_stage(c, 12, idx_off, step, s) : 0;
+        return 0;
     }
     MnistCtx p = *c;
-    static const int fwd[] = {0, 1, 2};
+    static const int fwd[] = {17, 2};
     static const int norm_pass[] = {3, 4, 6, 7, 11};
     static const int clip_unfused[] = {3, 5, 8, 9};
     static const int clip_fused[] = {3, 5, 12};  // SGD + noise inside fc1_wgrad / finalize
@@ -1571,7 +1754,8 @@ static int train_step_micro(const MnistCtx* c, int step, hipStream_t s) {
     for (int mb = 0; mb < c->micro; ++mb) {
         const int ts = step * c->micro + mb;
         p.accumulate = mb > 0 ? 1 : 0;
-        for (int stage = 0; stage <= 8; ++stage) {
+        static const int micro_seq[] = {17, 2, 3, 4, 5, 6, 7, 8};
+        for (int stage : micro_seq) {
             const int rc = nf_mnist_stage(&p, stage, ts * c->B, ts, s);
             if (rc) return rc;
         }
@@ -1602,7 +1786,8 @@ int nf_mnist_train_steps(const MnistCtx* c, int first_step, int steps, hipStream
 // Forward + loss/accuracy only (ctx->train must be 0 and eval_out set).
 int nf_mnist_eval_step(const MnistCtx* c, int idx_off, int step, hipStream_t s) {
     if (c->train != 0 || c->eval_out == nullptr) return -11;
-    for (int stage = 0; stage <= 3; ++stage) {
+    static const int eval_seq[] = {17, 2, 3};
+    for (int stage : eval_seq) {
         const int rc = nf_mnist_stage(c, stage, idx_off, step, s);
         if (rc) return rc;
     }

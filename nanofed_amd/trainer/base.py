@@ -49,6 +49,10 @@ class TrainingMetrics:
     epoch: int
     batch: int
     samples_processed: int
+    # which implementation produced the numbers: "torch" (PyTorch ops in the dtype of the
+    # model) or "native" (the hand-written bf16 kernels of nanofed_amd.engine); not part of
+    # the wire format (``to_dict``)
+    backend: str = "torch"
 
     def to_dict(self) -> dict[str, float | int]:
         """The three fields that travel to the server with an update."""

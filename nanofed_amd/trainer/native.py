@@ -13,7 +13,8 @@ model's weights are copied into a one-client arena, the epoch is one hipGraph
 replay, and the trained weights are copied back into the module.  Anything else
 takes the PyTorch path unchanged.
 
-``NANOFED_NATIVE_TRAINER=0`` switches the route off.
+The choice belongs to the trainer's ``native`` argument (``TorchTrainer(config,
+native="auto" | True | False)``); ``NANOFED_NATIVE_TRAINER=0`` turns "auto" off.
 """
 
 from __future__ import annotations
@@ -51,36 +52,49 @@ def _raw_dataset(dataset: Any) -> tuple[Any, np.ndarray] | None:
     return None
 
 
-def native_epoch_supported(trainer: Any, model: Any, dataloader: Any, optimizer: Any) -> bool:
-    """True when ``train_epoch(model, dataloader, optimizer, ...)`` is the step the
-    native MNIST kernels implement."""
+def native_epoch_unsupported_reason(trainer: Any, model: Any, dataloader: Any,
+                                    optimizer: Any) -> str | None:
+    """None when ``train_epoch(model, dataloader, optimizer, ...)`` is the step the native
+    MNIST kernels implement, otherwise what stands in the way."""
     from nanofed_amd.models import MNISTModel
 
-    if os.environ.get("NANOFED_NATIVE_TRAINER", "1") == "0":
-        return False
     cfg = trainer._config
     if torch.device(cfg.device).type != "cuda" or not torch.cuda.is_available():
-        return False
-    if type(model) is not MNISTModel or cfg.max_batches is not None or trainer._callbacks:
-        return False
+        return f"the trainer's device is {cfg.device!r}, not a HIP device"
+    if type(model) is not MNISTModel:
+        return f"the model is a {type(model).__name__}, not the MNISTModel the kernels implement"
+    if cfg.max_batches is not None:
+        return "max_batches cuts epochs short"
+    if trainer._callbacks:
+        return "callbacks want per-batch host values"
     if not isinstance(dataloader, DataLoader) or dataloader.batch_size is None:
-        return False
+        return "the data comes from something else than a batched DataLoader"
     if not 1 <= dataloader.batch_size <= MAX_NATIVE_BATCH:
-        return False
+        return f"the batch size {dataloader.batch_size} is outside 1..{MAX_NATIVE_BATCH}"
     if dataloader.drop_last or not isinstance(dataloader.sampler, RandomSampler):
-        return False
+        return "the loader does not draw random batches with the partial last batch kept"
     raw = _raw_dataset(dataloader.dataset)
     if raw is None or tuple(raw[0].images_u8.shape[1:]) != (1, 28, 28):
-        return False
+        return "the dataset did not keep its uint8 images (images_u8 / labels_i64, 1x28x28)"
     if type(optimizer) is not torch.optim.SGD or len(optimizer.param_groups) != 1:
-        return False
+        return "the optimizer is not plain SGD with one parameter group"
     group = optimizer.param_groups[0]
     if group.get("momentum", 0) or group.get("nesterov", False) or group.get("dampening", 0):
-        return False
+        return "the optimizer uses momentum"
     if group.get("maximize", False):
-        return False
+        return "the optimizer maximizes"
     own = {id(p) for p in model.parameters()}
-    return {id(p) for p in group["params"]} == own
+    if {id(p) for p in group["params"]} != own:
+        return "the optimizer does not hold exactly the model's parameters"
+    return None
+
+
+def native_epoch_supported(trainer: Any, model: Any, dataloader: Any, optimizer: Any) -> bool:
+    """True when ``train_epoch(model, dataloader, optimizer, ...)`` is the step the
+    native MNIST kernels implement (and the route is not switched off)."""
+    if os.environ.get("NANOFED_NATIVE_TRAINER", "1") == "0":
+        return False
+    return native_epoch_unsupported_reason(trainer, model, dataloader, optimizer) is None
 
 
 class NativeEpochSession:
@@ -129,24 +143,46 @@ class NativeEpochSession:
             model.load_state_dict(arena.state_dict(self.device))
             loss, acc = metrics[0, M_LOSS].item(), metrics[0, M_ACC].item()
         return TrainingMetrics(loss=float(loss), accuracy=float(acc), epoch=epoch,
-                               batch=max(self.steps - 1, 0), samples_processed=self.samples)
+                               batch=max(self.steps - 1, 0), samples_processed=self.samples,
+                               backend="native")
 
 
-def native_session_for(trainer: Any, dataloader: DataLoader, optimizer: Any) -> NativeEpochSession:
+def _loader_signature(dataloader: DataLoader) -> tuple:
+    """What a session was built from: the dataset object, its length and the batch size.
+    A session is only reused for the loader it was built for while these still hold."""
+    dataset = dataloader.dataset
+    return (id(dataset), len(dataset), int(dataloader.batch_size))
+
+
+def native_session_for(trainer: Any, dataloader: DataLoader, optimizer: Any,
+                       factory: Any = None) -> NativeEpochSession:
     """The session of ``dataloader`` (built once: it places the shard in HBM and
     captures the epoch graph); a new learning rate or weight decay builds a new one,
-    because they are arguments of the captured kernels."""
+    because they are arguments of the captured kernels.
+
+    Sessions are kept in a ``WeakKeyDictionary`` on the loader OBJECT: a session lives
+    exactly as long as its loader (a client that builds a new loader every round gets a
+    new session and the old one - shard, arena, graphs - is released with the old
+    loader), and an address that the allocator hands out again cannot be mistaken for
+    the loader that used to live there."""
+    import weakref
+
     group = optimizer.param_groups[0]
     lr, wd = float(group["lr"]), float(group.get("weight_decay", 0.0))
-    cache = trainer.__dict__.setdefault("_native_sessions", {})
-    key = id(dataloader)
-    session = cache.get(key)
-    if session is None or session.lr != lr or session.wd != wd:
+    cache = trainer.__dict__.get("_native_sessions")
+    if cache is None:
+        cache = trainer.__dict__["_native_sessions"] = weakref.WeakKeyDictionary()
+    signature = _loader_signature(dataloader)
+    session = cache.get(dataloader)
+    if (session is None or session.lr != lr or session.wd != wd
+            or getattr(session, "signature", signature) != signature):
         Logger().info(
-            f"train_epoch runs on the native MNIST kernels ({len(dataloader.dataset)} samples, "
-            f"lr {lr}, one hipGraph per epoch)"
+            f"train_epoch runs on the native MNIST kernels (bf16 compute, fp32 master weights; "
+            f"{len(dataloader.dataset)} samples, lr {lr}, one hipGraph per epoch)"
         )
+        make = factory or NativeEpochSession
         with _NATIVE_LOCK:
-            session = NativeEpochSession(dataloader, torch.device(trainer._config.device), lr, wd)
-        cache[key] = session
+            session = make(dataloader, torch.device(trainer._config.device), lr, wd)
+        session.signature = signature
+        cache[dataloader] = session
     return session

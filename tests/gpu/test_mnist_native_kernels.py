@@ -109,6 +109,27 @@ def test_conv2_fwd_relu_pool(env):
         assert torch.equal((mask & 3)[clear], q_ref[clear])
 
 
+@pytest.mark.parametrize("split", [1, 3])
+def test_fused_conv1_conv2_forward_equals_the_two_kernels(env, split):
+    """conv12_fwd (conv1 into the LDS image that conv2 reads, one launch) against
+    conv1_fwd followed by conv2_fwd: the same bits in every output, for whole-image and
+    for per-band workgroups."""
+    buf = env["buf"]
+    saved = buf.ctx.split
+    buf.ctx.split = split
+    try:
+        run(buf, "conv1_fwd", "conv2_fwd")
+        want = [t.clone() for t in (buf.a1, buf.a1mask, buf.p2, buf.pmask)]
+        for t in (buf.a1, buf.a1mask, buf.p2, buf.pmask):
+            t.fill_(7)
+        run(buf, "conv12_fwd")
+        for got, ref, name in zip((buf.a1, buf.a1mask, buf.p2, buf.pmask), want,
+                                  ("a1", "a1mask", "p2", "pmask")):
+            assert torch.equal(got, ref), name
+    finally:
+        buf.ctx.split = saved
+
+
 def _da2_from_pooled(buf, k):
     """d(conv2 out) [B,24,24,64] as the conv2 backward kernels expand it from
     the pooled gradient and the arg-max code."""

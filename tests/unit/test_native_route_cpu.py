@@ -75,3 +75,78 @@ def test_only_the_exact_native_step_qualifies(monkeypatch):
     assert not native.native_epoch_supported(capped, model, _loader(), sgd)
     monkeypatch.setenv("NANOFED_NATIVE_TRAINER", "0")
     assert not native.native_epoch_supported(trainer, model, _loader(), sgd)
+
+
+class _FakeSession:
+    """Stands in for NativeEpochSession (which needs a GPU): remembers what it was built from."""
+
+    built = 0
+
+    def __init__(self, dataloader, device, lr, wd):
+        type(self).built += 1
+        self.lr, self.wd = lr, wd
+        self.first_label = int(dataloader.dataset.labels_i64[0]) if hasattr(
+            dataloader.dataset, "labels_i64") else None
+
+
+def test_a_session_belongs_to_its_loader_object_and_dies_with_it(monkeypatch):
+    """The cache is keyed on the loader itself (weakly), not on its address: a second loader
+    over other data never gets the first one's session, a loader that is gone takes its
+    session (HBM shard, graphs) with it, and a new learning rate builds a new session."""
+    import gc
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    trainer = TorchTrainer(TrainingConfig(epochs=1, batch_size=64, learning_rate=0.1, device="cuda"))
+    model = MNISTModel()
+    sgd = torch.optim.SGD(model.parameters(), lr=0.1)
+    _FakeSession.built = 0
+    a, b = _loader(n=128), _loader(n=192)
+    sa = native.native_session_for(trainer, a, sgd, factory=_FakeSession)
+    assert native.native_session_for(trainer, a, sgd, factory=_FakeSession) is sa
+    sb = native.native_session_for(trainer, b, sgd, factory=_FakeSession)
+    assert sb is not sa and _FakeSession.built == 2
+    cache = trainer.__dict__["_native_sessions"]
+    assert len(cache) == 2
+    # the loader dies: so does its session, whatever object gets that address next
+    del a, sa
+    gc.collect()
+    assert len(cache) == 1
+    for _ in range(8):  # new loaders, some of which may land on the freed address
+        fresh = _loader(n=64)
+        s = native.native_session_for(trainer, fresh, sgd, factory=_FakeSession)
+        assert s is not sb and len(cache) == 2
+        del fresh, s
+        gc.collect()
+        assert len(cache) == 1
+    # the dataset behind a loader is replaced: the session is rebuilt
+    b.__dict__["dataset"] = _loader(n=320).dataset  # (DataLoader guards normal assignment)
+    sb2 = native.native_session_for(trainer, b, sgd, factory=_FakeSession)
+    assert sb2 is not sb
+    # a new learning rate is an argument of the captured kernels
+    sgd.param_groups[0]["lr"] = 0.05
+    assert native.native_session_for(trainer, b, sgd, factory=_FakeSession) is not sb2
+
+
+def test_native_argument_of_the_trainer(monkeypatch):
+    import pytest
+
+    from nanofed_amd.core.exceptions import DeviceError
+
+    cfg = TrainingConfig(epochs=1, batch_size=64, learning_rate=0.1, device="cpu")
+    model = MNISTModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    with pytest.raises(ValueError):
+        TorchTrainer(cfg, native="yes")
+    forced = TorchTrainer(cfg, native=True)
+    with pytest.raises(DeviceError, match="not a HIP device"):
+        forced.train_epoch(model, _loader(), opt, 0)
+    off = TorchTrainer(cfg, native=False)
+    m = off.train_epoch(model, _loader(), opt, 0)
+    assert m.backend == "torch" and off.last_backend == "torch"
+    assert "backend" not in m.to_dict()  # the wire format keeps the reference's three fields
+    # "auto" on a device: the reason why a call does not qualify is available
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    auto = TorchTrainer(TrainingConfig(epochs=1, batch_size=64, learning_rate=0.1, device="cuda"))
+    adam = torch.optim.Adam(model.parameters(), lr=0.1)
+    assert "plain SGD" in native.native_epoch_unsupported_reason(auto, model, _loader(), adam)
+    assert native.native_epoch_unsupported_reason(auto, model, _loader(), opt) is None
