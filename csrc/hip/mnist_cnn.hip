@@ -596,38 +596,66 @@ __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-// 8 batch rows per workgroup; thread = (row r, 4 consecutive hidden units).
+// Sum over the 32 lanes of a wave half, in every one of them: quad and row butterflies as
+// DPP adds (one instruction each), then the two 16-lane rows of the half exchange their
+// sums (v_permlane16_swap).
+template <int kCtrl>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
+// 8 batch rows per workgroup; thread = (row r, 4 consecutive hidden units); a row is one
+// half of a wave.  Everything up to d(logits) happens in registers (the 32 lanes of a row
+// reduce their partial logits with DPP adds and all hold the row's logits), so the kernel
+// has one barrier: before the sums over the 8 rows (fc2's weight gradient, the bias
+// gradients, the loss).  The slabs, fc2's weights and the label are fetched first, all at
+// once - the kernel is a chain of latencies, not of arithmetic.
 __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int step) {
     if (client_idle(c, blockIdx.y)) return;
     const int hb = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     __shared__ float h1s[kHeadRows][132];
-    __shared__ float dm[kHeadRows][132];
-    __shared__ float w2[10][132];
-    __shared__ float lg[kHeadRows][12];
+    __shared__ float dvs[kHeadRows][132];  // d(h1 pre-activation)
     __shared__ float dl[kHeadRows][12];
     __shared__ float red[2][kHeadRows];
     const int r0 = hb * kHeadRows;
     const float* wa = c.arena + g * c.arena_stride;
-    // the label is two dependent loads away: start them before anything else
-    int y = 0;
-    if (tid < kHeadRows) y = c.labels[c.idx[g * c.idx_stride + idx_off + r0 + tid]];
-    for (int i = tid; i < 1280; i += 256) w2[i >> 7][i & 127] = wa[c.off_f2w + i];
-
-    // A: reduce the split-K slabs, bias, ReLU, dropout
     const int r = tid >> 5, j0 = (tid & 31) * 4;
     const int b = r0 + r;
+    // the label is two dependent loads away: start them before anything else
+    const int y = c.labels[c.idx[g * c.idx_stride + idx_off + b]];
+    const float* base = c.fc1_slabs + (static_cast<long>(g) * c.S * c.B + b) * 128 + j0;
+    const long sstride = static_cast<long>(c.B) * 128;
+    // all slabs in flight at once (check_ctx pins S to kFc1S)
+    float4 sl[kFc1S];
+#pragma unroll
+    for (int s = 0; s < kFc1S; ++s) sl[s] = *reinterpret_cast<const float4*>(base + s * sstride);
+    // fc2: this thread's 4 columns of the 10 rows, and the biases
+    float4 w2r[10];
+#pragma unroll
+    for (int o = 0; o < 10; ++o) w2r[o] = *reinterpret_cast<const float4*>(wa + c.off_f2w + o * 128 + j0);
+    const float4 bv = *reinterpret_cast<const float4*>(wa + c.off_f1b + j0);
+    float b2[10];
+#pragma unroll
+    for (int o = 0; o < 10; ++o) b2[o] = wa[c.off_f2b + o];
+    const int nv = c.nvalid[g * c.nvalid_stride + step];
+    const int nt = c.ntotal != nullptr ? c.ntotal[g * c.nvalid_stride + step] : nv;
+
+    // A: reduce the split-K slabs (two chains, even and odd slabs), bias, ReLU, dropout
+    float h[4], dm[4];
     {
-        const float4 bv = *reinterpret_cast<const float4*>(wa + c.off_f1b + j0);
         float4 s0 = bv, s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* base = c.fc1_slabs + (static_cast<long>(g) * c.S * c.B + b) * 128 + j0;
-        const long sstride = static_cast<long>(c.B) * 128;
-        // all slabs in flight at once (check_ctx pins S to kFc1S)
 #pragma unroll
         for (int s = 0; s < kFc1S; s += 2) {
-            const float4 v0 = *reinterpret_cast<const float4*>(base + s * sstride);
-            const float4 v1 = *reinterpret_cast<const float4*>(base + (s + 1) * sstride);
-            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            s0.x += sl[s].x; s0.y += sl[s].y; s0.z += sl[s].z; s0.w += sl[s].w;
+            s1.x += sl[s + 1].x; s1.y += sl[s + 1].y; s1.z += sl[s + 1].z; s1.w += sl[s + 1].w;
         }
         const float acc[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
         float u[4] = {1.f, 1.f, 1.f, 1.f};
@@ -640,66 +668,93 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            bool alive = acc[e] > 0.f;
-            if (c.train) alive = alive && (u[e] >= c.p_drop2);
-            h1s[r][j0 + e] = alive ? acc[e] * sc : 0.f;
-            dm[r][j0 + e] = alive ? sc : 0.f;
+            const bool alive = (acc[e] > 0.f) & (!c.train | (u[e] >= c.p_drop2));
+            h[e] = alive ? acc[e] * sc : 0.f;
+            dm[e] = alive ? sc : 0.f;
         }
+        *reinterpret_cast<float4*>(&h1s[r][j0]) = make_float4(h[0], h[1], h[2], h[3]);
     }
-    __syncthreads();
 
-    // B: logits
-    if (tid < kHeadRows * 10) {
-        const int rr = tid / 10, o = tid - rr * 10;
-        float acc = wa[c.off_f2b + o];
-#pragma unroll 8
-        for (int j = 0; j < 128; ++j) acc = fmaf(h1s[rr][j], w2[o][j], acc);
-        lg[rr][o] = acc;
+    // B: logits of the row, in every lane of its wave half
+    float lg[10];
+#pragma unroll
+    for (int o = 0; o < 10; ++o) {
+        float p = h[0] * w2r[o].x;
+        p = fmaf(h[1], w2r[o].y, p);
+        p = fmaf(h[2], w2r[o].z, p);
+        p = fmaf(h[3], w2r[o].w, p);
+        lg[o] = half_wave_sum(p) + b2[o];
     }
-    __syncthreads();
 
     // C: log-softmax, NLL, accuracy, d(logits)
-    const int nv = c.nvalid[g * c.nvalid_stride + step];
-    if (tid < kHeadRows) {
-        const int bb = r0 + tid;
-        const bool valid = bb < nv;
-        float m = lg[tid][0];
-        int pred = 0;
-        for (int o = 1; o < 10; ++o)
-            if (lg[tid][o] > m) { m = lg[tid][o]; pred = o; }
-        float se = 0.f;
-        for (int o = 0; o < 10; ++o) se += __expf(lg[tid][o] - m);
-        const float lse = m + __logf(se);
-        const int nt = c.ntotal != nullptr ? c.ntotal[g * c.nvalid_stride + step] : nv;
-        const float inv = nt > 0 ? 1.0f / static_cast<float>(nt) : 0.f;
-        for (int o = 0; o < 10; ++o) {
-            const float p = __expf(lg[tid][o] - lse);
-            dl[tid][o] = valid ? (p - (o == y ? 1.f : 0.f)) * inv : 0.f;
+    const bool valid = b < nv;
+    float m = lg[0];
+    int pred = 0;
+#pragma unroll
+    for (int o = 1; o < 10; ++o)
+        if (lg[o] > m) { m = lg[o]; pred = o; }
+    float se = 0.f;
+#pragma unroll
+    for (int o = 0; o < 10; ++o) se += __expf(lg[o] - m);
+    const float lse = m + __logf(se);
+    const float inv = nt > 0 ? 1.0f / static_cast<float>(nt) : 0.f;
+    float dlr[10];
+    float ly = 0.f;
+#pragma unroll
+    for (int o = 0; o < 10; ++o) {
+        const float p = __expf(lg[o] - lse);
+        dlr[o] = valid ? (p - (o == y ? 1.f : 0.f)) * inv : 0.f;
+        ly = o == y ? lg[o] : ly;
+    }
+    if (c.dp_pass != 0) {
+        const long bi = static_cast<long>(g) * c.B + b;
+        if (c.dp_pass == 1) {
+            // per-sample gradient of fc2: dl (x) h1 and dl
+            float hq = fmaf(h[0], h[0], fmaf(h[1], h[1], fmaf(h[2], h[2], h[3] * h[3])));
+            const float hsq = 1.f + half_wave_sum(hq);
+            float dsq = 0.f;
+#pragma unroll
+            for (int o = 0; o < 10; ++o) dsq = fmaf(dlr[o], dlr[o], dsq);
+            if ((tid & 31) == 0) c.dp_normsq[bi * 4 + 0] = hsq * dsq;
+        } else {
+            const float scl = c.dp_rowscale[bi];
+#pragma unroll
+            for (int o = 0; o < 10; ++o) dlr[o] *= scl;
         }
-        red[0][tid] = valid ? (lse - lg[tid][y]) : 0.f;
-        red[1][tid] = (valid && pred == y) ? 1.f : 0.f;
+    }
+    if ((tid & 31) == 0) {
+#pragma unroll
+        for (int o = 0; o < 10; ++o) dl[r][o] = dlr[o];
+        red[0][r] = valid ? (lse - ly) : 0.f;
+        red[1][r] = (valid && pred == y) ? 1.f : 0.f;
+    }
+    const bool eval_only = !c.train && c.eval_out != nullptr;
+    if (!eval_only) {
+        // E: d(h1 pre-activation), from registers
+        bf16x4 o4;
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int o = 0; o < 10; ++o) {
+                const float w = e == 0 ? w2r[o].x : (e == 1 ? w2r[o].y : (e == 2 ? w2r[o].z : w2r[o].w));
+                v = fmaf(dlr[o], w, v);
+            }
+            v *= dm[e];
+            v4[e] = v;
+            o4[e] = f2bf(v);
+        }
+        *reinterpret_cast<bf16x4*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o4;
+        *reinterpret_cast<float4*>(&dvs[r][j0]) = make_float4(v4[0], v4[1], v4[2], v4[3]);
     }
     __syncthreads();
 
-    if (c.dp_pass != 0 && tid < kHeadRows) {
-        const long bi = static_cast<long>(g) * c.B + r0 + tid;
-        if (c.dp_pass == 1) {
-            // per-sample gradient of fc2: dl (x) h1 and dl
-            float hsq = 1.f, dsq = 0.f;
-            for (int j = 0; j < 128; ++j) hsq = fmaf(h1s[tid][j], h1s[tid][j], hsq);
-            for (int o = 0; o < 10; ++o) dsq = fmaf(dl[tid][o], dl[tid][o], dsq);
-            c.dp_normsq[bi * 4 + 0] = hsq * dsq;
-        } else {
-            const float sc = c.dp_rowscale[bi];
-            for (int o = 0; o < 10; ++o) dl[tid][o] *= sc;
-        }
-    }
-    __syncthreads();
     float loss_sum = 0.f, correct = 0.f;
     if (tid == 0) {
         for (int i = 0; i < kHeadRows; ++i) { loss_sum += red[0][i]; correct += red[1][i]; }
     }
-    if (!c.train && c.eval_out != nullptr) {
+    if (eval_only) {
         // one slot per workgroup, overwritten every step: the host adds the slots of
         // the clients that had a batch, in a fixed order (no float atomics)
         if (tid == 0) {
@@ -724,24 +779,9 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         for (int rr = 0; rr < kHeadRows; ++rr) acc += dl[rr][tid];
         part[1280 + tid] = acc;
     }
-    // E: d(h1 pre-activation)
-    {
-        bf16x4 o4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = 0.f;
-#pragma unroll
-            for (int o = 0; o < 10; ++o) v = fmaf(dl[r][o], w2[o][j0 + e], v);
-            v *= dm[r][j0 + e];
-            o4[e] = f2bf(v);
-            dm[r][j0 + e] = v;
-        }
-        *reinterpret_cast<bf16x4*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o4;
-    }
-    __syncthreads();
     if (tid < 128) {
         float acc = 0.f;
-        for (int rr = 0; rr < kHeadRows; ++rr) acc += dm[rr][tid];
+        for (int rr = 0; rr < kHeadRows; ++rr) acc += dvs[rr][tid];
         part[1296 + tid] = acc;
     }
     if (tid == 0) { part[1424] = loss_sum; part[1425] = correct; }
@@ -1068,48 +1108,72 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
     const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
     const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
 
+    // One item = one pooled pixel x 8 channels: a single load of the pooled
+    // gradient and the arg-max codes feeds the four positions of its 2x2 window.
+    // Pooled rows/columns one step outside the image produce the zero halo.
+    // Loads are unconditional (clamped coordinates) so that several are in flight,
+    // and the loads of chunk + 1 are issued before the matrix loop of chunk, into
+    // registers that wait there (24 per lane).
+    struct DgChunk {
+        int mb0, nmb, oy_base, nrows, py_base, nitems;
+        __device__ __forceinline__ explicit DgChunk(int chunk) {
+            mb0 = chunk * 8;
+            nmb = chunk < 2 ? 8 : 6;
+            const int pix0 = mb0 * 32;
+            const int pixl = min(pix0 + nmb * 32, kA1Pix) - 1;
+            const int ymin = pix0 / 26, ymax = pixl / 26;
+            oy_base = ymin - 2;
+            nrows = ymax - ymin + 3;
+            py_base = ((oy_base + 2) >> 1) - 1;  // floor(oy_base / 2), oy_base >= -2
+            const int nprow = ((oy_base + nrows + 1) >> 1) - py_base;
+            nitems = nprow * 14 * 8;
+        }
+    };
+    uint4 pv[4];
+    uint2 pm[4];
+#define NF_DG_ISSUE(chunk_)                                                                  \
+    {                                                                                        \
+        const DgChunk ck_(chunk_);                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+            const int itc = min(tid + i * 256, ck_.nitems - 1);                              \
+            const int part = itc & 7, pi = itc >> 3;                                         \
+            const int prow = pi / 14, pcol = pi - prow * 14;                                 \
+            const int py = ck_.py_base + prow, px = pcol - 1;                                \
+            const int pooled = min(max(py, 0), 11) * 12 + min(max(px, 0), 11);               \
+            pv[i] = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);       \
+            pm[i] = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);      \
+        }                                                                                    \
+    }
+    NF_DG_ISSUE(chunk0)
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
-        const int mb0 = chunk * 8;
-        const int nmb = chunk < 2 ? 8 : 6;
-        const int pix0 = mb0 * 32;
-        const int pixl = min(pix0 + nmb * 32, kA1Pix) - 1;
-        const int ymin = pix0 / 26, ymax = pixl / 26;
-        const int oy_base = ymin - 2;
-        const int nrows = ymax - ymin + 3;
+        const DgChunk ck(chunk);
+        const int mb0 = ck.mb0, nmb = ck.nmb, oy_base = ck.oy_base, nrows = ck.nrows;
         __syncthreads();
-        // One item = one pooled pixel x 8 channels: a single load of the pooled
-        // gradient and the arg-max codes feeds the four positions of its 2x2 window.
-        // Pooled rows/columns one step outside the image produce the zero halo.
-        // Loads are unconditional (clamped coordinates) so that the unrolled
-        // iterations keep several in flight.
-        const int py_base = ((oy_base + 2) >> 1) - 1;  // floor(oy_base / 2), oy_base >= -2
-        const int nprow = ((oy_base + nrows + 1) >> 1) - py_base;
-        const int nitems = nprow * 14 * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int it = tid + i * 256;
-            const int itc = min(it, nitems - 1);
+            const int itc = min(it, ck.nitems - 1);
             const int part = itc & 7, pi = itc >> 3;
             const int prow = pi / 14, pcol = pi - prow * 14;
-            const int py = py_base + prow, px = pcol - 1;
+            const int py = ck.py_base + prow, px = pcol - 1;
             const bool inside = py >= 0 && py < 12 && px >= 0 && px < 12;
-            const int pooled = min(max(py, 0), 11) * 12 + min(max(px, 0), 11);
-            uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
-            const uint2 m = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);
+            uint4 v = pv[i];
             if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
-            const PoolWindow win(v, m, lut);
+            const PoolWindow win(v, pm[i], lut);
             // window rows 2 * py and 2 * py + 1 of the image, relative to the patch
             const int pr = 2 * py - oy_base;
             char* const dst = smem + nfix::mnist_dg_off(pr, 2 * px + 2, part);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int prq = pr + (q >> 1);
-                if (it < nitems && prq >= 0 && prq < nrows)
+                if (it < ck.nitems && prq >= 0 && prq < nrows)
                     *reinterpret_cast<uint4*>(dst + (q >> 1) * kDgRowPitch + (q & 1) * kDgPixPitch) =
                         win.at(q);
             }
         }
+        if (chunk + 1 < chunk1) NF_DG_ISSUE(chunk + 1)
         __syncthreads();
+#undef NF_DG_ISSUE
 
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
