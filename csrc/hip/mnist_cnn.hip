@@ -112,6 +112,9 @@ struct MnistCtx {
     int accumulate;         // this launch adds to `grad` instead of overwriting it (filled in per micro-batch)
     const int32_t* ntotal;  // [G][nvalid_stride] or nullptr
     int bwd_triple;         // 1: conv2_wgrad shares the launch of conv2_dgrad + fc1_wgrad
+    // non-null: the images are rows of normalised floats [N][784] (a batch handed over as a
+    // tensor, e.g. by PrivateTrainer.train_batch) instead of the uint8 dataset
+    const float* images_f32;
 };
 
 }  // extern "C"
@@ -131,6 +134,24 @@ __device__ __forceinline__ bool client_idle(const MnistCtx& c, int g) {
 
 __device__ __forceinline__ unsigned long long client_seed(const MnistCtx& c, int g) {
     return c.seed + 0x9E3779B97F4A7C15ull * static_cast<unsigned long long>(c.client_base + g + 1);
+}
+
+// The normalised input image of dataset row `row` into xs[0..783] (threads 0..195, four
+// pixels each): from the uint8 dataset (normalisation fused into the load) or, when the
+// batch came as a float tensor, as it is.
+__device__ __forceinline__ void load_image(const MnistCtx& c, int row, int tid, float* xs) {
+    if (tid >= 196) return;
+    if (c.images_f32 != nullptr) {
+        const float4 v = reinterpret_cast<const float4*>(c.images_f32 + static_cast<long>(row) * 784)[tid];
+        xs[4 * tid + 0] = v.x; xs[4 * tid + 1] = v.y; xs[4 * tid + 2] = v.z; xs[4 * tid + 3] = v.w;
+        return;
+    }
+    const uchar4 v = reinterpret_cast<const uchar4*>(c.images + static_cast<long>(row) * 784)[tid];
+    const float k = 1.0f / 255.0f;
+    xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
+    xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
+    xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
+    xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
 }
 
 // ---------------------------------------------------------------------------
@@ -156,18 +177,8 @@ conv1_fwd_kernel(MnistCtx c, int idx_off) {
     const int g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     __shared__ float xs[784 + 4];  // the image, then the 1.0 that multiplies the bias
-    const int row = c.idx[g * c.idx_stride + idx_off + b];
-    const uint8_t* img = c.images + static_cast<long>(row) * 784;
-    if (tid < 196) {
-        const uchar4 v = reinterpret_cast<const uchar4*>(img)[tid];
-        const float k = 1.0f / 255.0f;
-        xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
-        xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
-        xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
-        xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
-    } else if (tid == 196) {
-        xs[784] = 1.0f;
-    }
+    load_image(c, c.idx[g * c.idx_stride + idx_off + b], tid, xs);
+    if (tid == 196) xs[784] = 1.0f;
     // A operand: row = channel n, k = 2 s + h.  k = 0..8 the taps, k = 9 the bias.
     const float* wa = c.arena + g * c.arena_stride;
     float wk[5];
@@ -389,20 +400,8 @@ conv12_fwd_kernel(MnistCtx c, int idx_off) {
     const long img = static_cast<long>(g) * c.B + b;
 
     // input image (its loads are the longest dependent chain of the kernel: first)
-    {
-        const int row = c.idx[g * c.idx_stride + idx_off + b];
-        const uint8_t* im = c.images + static_cast<long>(row) * 784;
-        if (tid < 196) {
-            const uchar4 v = reinterpret_cast<const uchar4*>(im)[tid];
-            const float k = 1.0f / 255.0f;
-            xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
-            xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
-            xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
-            xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
-        } else if (tid == 196) {
-            xs[784] = 1.0f;
-        }
-    }
+    load_image(c, c.idx[g * c.idx_stride + idx_off + b], tid, xs);
+    if (tid == 196) xs[784] = 1.0f;
     // conv2's stationary operand through the (still unused) image area, as in conv2_fwd
     bf16x8 Bf[18];
     {
@@ -1082,17 +1081,9 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
     }
 
     {
-        const int row = c.idx[g * c.idx_stride + idx_off + b];
-        const uint8_t* im = c.images + static_cast<long>(row) * 784;
-        if (tid < 196) {
-            const uchar4 v = reinterpret_cast<const uchar4*>(im)[tid];
-            const float k = 1.0f / 255.0f;
-            xs[4 * tid + 0] = (v.x * k - c.mean) * c.inv_std;
-            xs[4 * tid + 1] = (v.y * k - c.mean) * c.inv_std;
-            xs[4 * tid + 2] = (v.z * k - c.mean) * c.inv_std;
-            xs[4 * tid + 3] = (v.w * k - c.mean) * c.inv_std;
+        load_image(c, c.idx[g * c.idx_stride + idx_off + b], tid, xs);
+        if (tid < 196)
             *reinterpret_cast<float4*>(xs + 784 + 4 * tid) = make_float4(1.f, 1.f, 1.f, 1.f);
-        }
         const uint32_t* am = c.a1mask + img * kA1Pix;
         for (int p = tid; p < kDgPixPad; p += 256) {
             const int y = p / 26, x = p - y * 26;
@@ -1108,72 +1099,48 @@ __device__ __forceinline__ void conv2_dgrad_body(const MnistCtx& c, int idx_off,
     const bf16* dp2img = c.dp2 + img * kP2Pix * kC2;
     const uint8_t* maskimg = c.pmask + img * kP2Pix * kC2;
 
-    // One item = one pooled pixel x 8 channels: a single load of the pooled
-    // gradient and the arg-max codes feeds the four positions of its 2x2 window.
-    // Pooled rows/columns one step outside the image produce the zero halo.
-    // Loads are unconditional (clamped coordinates) so that several are in flight,
-    // and the loads of chunk + 1 are issued before the matrix loop of chunk, into
-    // registers that wait there (24 per lane).
-    struct DgChunk {
-        int mb0, nmb, oy_base, nrows, py_base, nitems;
-        __device__ __forceinline__ explicit DgChunk(int chunk) {
-            mb0 = chunk * 8;
-            nmb = chunk < 2 ? 8 : 6;
-            const int pix0 = mb0 * 32;
-            const int pixl = min(pix0 + nmb * 32, kA1Pix) - 1;
-            const int ymin = pix0 / 26, ymax = pixl / 26;
-            oy_base = ymin - 2;
-            nrows = ymax - ymin + 3;
-            py_base = ((oy_base + 2) >> 1) - 1;  // floor(oy_base / 2), oy_base >= -2
-            const int nprow = ((oy_base + nrows + 1) >> 1) - py_base;
-            nitems = nprow * 14 * 8;
-        }
-    };
-    uint4 pv[4];
-    uint2 pm[4];
-#define NF_DG_ISSUE(chunk_)                                                                  \
-    {                                                                                        \
-        const DgChunk ck_(chunk_);                                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
-            const int itc = min(tid + i * 256, ck_.nitems - 1);                              \
-            const int part = itc & 7, pi = itc >> 3;                                         \
-            const int prow = pi / 14, pcol = pi - prow * 14;                                 \
-            const int py = ck_.py_base + prow, px = pcol - 1;                                \
-            const int pooled = min(max(py, 0), 11) * 12 + min(max(px, 0), 11);               \
-            pv[i] = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);       \
-            pm[i] = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);      \
-        }                                                                                    \
-    }
-    NF_DG_ISSUE(chunk0)
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
-        const DgChunk ck(chunk);
-        const int mb0 = ck.mb0, nmb = ck.nmb, oy_base = ck.oy_base, nrows = ck.nrows;
+        const int mb0 = chunk * 8;
+        const int nmb = chunk < 2 ? 8 : 6;
+        const int pix0 = mb0 * 32;
+        const int pixl = min(pix0 + nmb * 32, kA1Pix) - 1;
+        const int ymin = pix0 / 26, ymax = pixl / 26;
+        const int oy_base = ymin - 2;
+        const int nrows = ymax - ymin + 3;
         __syncthreads();
+        // One item = one pooled pixel x 8 channels: a single load of the pooled
+        // gradient and the arg-max codes feeds the four positions of its 2x2 window.
+        // Pooled rows/columns one step outside the image produce the zero halo.
+        // Loads are unconditional (clamped coordinates) so that the unrolled
+        // iterations keep several in flight.
+        const int py_base = ((oy_base + 2) >> 1) - 1;  // floor(oy_base / 2), oy_base >= -2
+        const int nprow = ((oy_base + nrows + 1) >> 1) - py_base;
+        const int nitems = nprow * 14 * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int it = tid + i * 256;
-            const int itc = min(it, ck.nitems - 1);
+            const int itc = min(it, nitems - 1);
             const int part = itc & 7, pi = itc >> 3;
             const int prow = pi / 14, pcol = pi - prow * 14;
-            const int py = ck.py_base + prow, px = pcol - 1;
+            const int py = py_base + prow, px = pcol - 1;
             const bool inside = py >= 0 && py < 12 && px >= 0 && px < 12;
-            uint4 v = pv[i];
+            const int pooled = min(max(py, 0), 11) * 12 + min(max(px, 0), 11);
+            uint4 v = *reinterpret_cast<const uint4*>(dp2img + pooled * kC2 + part * 8);
+            const uint2 m = *reinterpret_cast<const uint2*>(maskimg + pooled * kC2 + part * 8);
             if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
-            const PoolWindow win(v, pm[i], lut);
+            const PoolWindow win(v, m, lut);
             // window rows 2 * py and 2 * py + 1 of the image, relative to the patch
             const int pr = 2 * py - oy_base;
             char* const dst = smem + nfix::mnist_dg_off(pr, 2 * px + 2, part);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int prq = pr + (q >> 1);
-                if (it < ck.nitems && prq >= 0 && prq < nrows)
+                if (it < nitems && prq >= 0 && prq < nrows)
                     *reinterpret_cast<uint4*>(dst + (q >> 1) * kDgRowPitch + (q & 1) * kDgPixPitch) =
                         win.at(q);
             }
         }
-        if (chunk + 1 < chunk1) NF_DG_ISSUE(chunk + 1)
         __syncthreads();
-#undef NF_DG_ISSUE
 
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {

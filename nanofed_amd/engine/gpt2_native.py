@@ -305,17 +305,14 @@ class GPT2NativeTrainer(GroupTrainer):
     def _off(self, name: str) -> int:
         return self.layout[name].offset
 
-    def _gemm(self, layout: int, a: torch.Tensor, b_ptr: int, c_ptr: int, M: int, N: int, K: int,
-              lda: int, ldb: int, ldc: int, Gn: int, sa: int, sb: int, sc: int,
-              bias: Ref | None = None, c2: torch.Tensor | None = None) -> None:
+    def _gemm(self, layout: int, a: torch.Tensor, b: "torch.Tensor | Ref", c: "torch.Tensor | Ref",
+              M: int, N: int, K: int, lda: int, ldb: int, ldc: int, Gn: int, sa: int, sb: int,
+              sc: int, bias: Ref | None = None, c2: torch.Tensor | None = None) -> None:
         need = go.gemm_slab_floats(M, N, K, layout, Gn)
         if need > self._gslabs.numel():
             self._gslabs = torch.empty(need, dtype=torch.float32, device=self.device)
-        go.gemm_batched(layout, a.data_ptr(), b_ptr, c_ptr, M, N, K, lda, ldb, ldc, Gn, sa, sb, sc,
-                        self._gslabs, go._stream(a),
-                        bias=bias.ptr.value if bias is not None else None,
-                        sbias=bias.stride if bias is not None else 0,
-                        c2=c2.data_ptr() if c2 is not None else None)
+        go.gemm_batched(layout, a, b, c, M, N, K, lda, ldb, ldc, Gn, sa, sb, sc,
+                        self._gslabs, go._stream(a), bias=bias, c2=c2)
 
     def _glin_fwd(self, x: torch.Tensor, wname: str, bname: str | None, out: torch.Tensor,
                   g0: int, Gn: int, R: int, gelu_out: torch.Tensor | None = None,
@@ -325,7 +322,7 @@ class GPT2NativeTrainer(GroupTrainer):
         N, K = self.layout[wname].shape
         w = Ref(self.shadow[g0:], self._off(wname))
         bias = Ref(self.shadow[g0:], self._off(bname)) if bname is not None else None
-        self._gemm(gemm_ops.NT, x, w.ptr.value, out.data_ptr(), R, n_out or N, K, x.stride(0), K,
+        self._gemm(gemm_ops.NT, x, w, out, R, n_out or N, K, x.stride(0), K,
                    out.stride(0), Gn, R * x.stride(0), w.stride, R * out.stride(0), bias, gelu_out)
 
     def _glin_dgrad(self, dy: torch.Tensor, wname: str, out: torch.Tensor, g0: int, Gn: int,
@@ -333,7 +330,7 @@ class GPT2NativeTrainer(GroupTrainer):
         """out[g] = dy[g] w[g]; dy ``[Gn * R, >= N]``, out ``[Gn * R, K]``."""
         N, K = self.layout[wname].shape
         w = Ref(self.shadow[g0:], self._off(wname))
-        self._gemm(gemm_ops.NN, dy, w.ptr.value, out.data_ptr(), R, K, n_in or N, dy.stride(0), K,
+        self._gemm(gemm_ops.NN, dy, w, out, R, K, n_in or N, dy.stride(0), K,
                    out.stride(0), Gn, R * dy.stride(0), w.stride, R * out.stride(0))
 
     def _glin_wgrad(self, dy: torch.Tensor, x: torch.Tensor, wname: str, Gn: int, R: int,
@@ -341,7 +338,7 @@ class GPT2NativeTrainer(GroupTrainer):
         """grad(w)[g] = dy[g]^T x[g], written into the group's gradient rows."""
         N, K = self.layout[wname].shape
         dw = Ref(self._ggrads, self._off(wname))
-        self._gemm(gemm_ops.TN, dy, x.data_ptr(), dw.ptr.value, n_out or N, K, R, dy.stride(0),
+        self._gemm(gemm_ops.TN, dy, x, dw, n_out or N, K, R, dy.stride(0),
                    x.stride(0), K, Gn, R * dy.stride(0), R * x.stride(0), dw.stride)
 
     def _gstep(self, g0: int, Gn: int, tokens: torch.Tensor) -> None:

@@ -90,6 +90,7 @@ class MnistCtx(ctypes.Structure):
         ("ragged", c_int), ("cur_step", c_int),
         ("micro", c_int), ("accumulate", c_int), ("ntotal", c_void_p),
         ("bwd_triple", c_int),
+        ("images_f32", c_void_p),
     ]
 
 

@@ -248,12 +248,12 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             pre = d["tiles"]
         else:
             if u is self._stem:
-                b_ptr, ldb, sb = bufs["wpad"].data_ptr(), STEM_K, 64 * STEM_K
+                b_ptr, ldb, sb = bufs["wpad"], STEM_K, 64 * STEM_K
             else:
                 go.im2col(x, d["col"], N, u.hin, u.hin, u.cin, u.hout, u.hout, u.k, u.stride,
                           u.pad, u.kp)
-                b_ptr, ldb, sb = w.ptr.value, u.kp, w.stride
-            go.gemm_batched(gemm_ops.NT, d["col"].data_ptr(), b_ptr, d["y"].data_ptr(), rows, C,
+                b_ptr, ldb, sb = w, u.kp, w.stride
+            go.gemm_batched(gemm_ops.NT, d["col"], b_ptr, d["y"], rows, C,
                             u.kp, u.kp, ldb, C, Gn, rows * u.kp, sb, rows * C, bufs["slabs"],
                             go._stream(d["y"]))
         go.bn_fwd(d["y"], res, d["out"], self._p32(g0, u.bn + ".weight"),
@@ -281,10 +281,10 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             return d["dx"]
         stream = go._stream(d["dyp"])
         if u is self._stem:
-            c_ptr, ldc, sc = bufs["dwpad"].data_ptr(), STEM_K, 64 * STEM_K
+            c_ptr, ldc, sc = bufs["dwpad"], STEM_K, 64 * STEM_K
         else:
-            c_ptr, ldc, sc = dw.ptr.value, u.kp, dw.stride
-        go.gemm_batched(gemm_ops.TN, d["dyp"].data_ptr(), d["col"].data_ptr(), c_ptr, C, u.kp, rows,
+            c_ptr, ldc, sc = dw, u.kp, dw.stride
+        go.gemm_batched(gemm_ops.TN, d["dyp"], d["col"], c_ptr, C, u.kp, rows,
                         C, u.kp, ldc, Gn, rows * C, rows * u.kp, sc, bufs["slabs"], stream)
         if u is self._stem:
             k = 9 * u.cin
@@ -292,7 +292,7 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             self._gradb[g0 : g0 + Gn, off : off + 64 * k].view(Gn, 64, k).copy_(
                 bufs["dwpad"][:, :, :k])
             return None
-        go.gemm_batched(gemm_ops.NN, d["dyp"].data_ptr(), w.ptr.value, d["dcol"].data_ptr(), rows,
+        go.gemm_batched(gemm_ops.NN, d["dyp"], w, d["dcol"], rows,
                         u.kp, C, C, u.kp, u.kp, Gn, rows * C, w.stride, rows * u.kp, bufs["slabs"],
                         stream)
         go.col2im(d["dcol"], d["dx"], N, u.hin, u.hin, u.cin, u.hout, u.hout, u.k, u.stride, u.pad,

@@ -41,6 +41,8 @@ def enabled(device: torch.device | None = None) -> bool:
 _slabs: dict[tuple[int, int], torch.Tensor] = {}
 
 NT, NN, TN = 0, 1, 2  # operand layouts (see csrc/hip/gemm_ops.hip)
+# (a tuple so that the CPU unit tests of the operand checks can admit host tensors)
+_DEVICE_TYPES: tuple[str, ...] = ("cuda",)
 
 
 def _check(t: torch.Tensor, name: str) -> None:
@@ -120,6 +122,31 @@ def _launch(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M:
         raise DeviceError("gemm: bias must be a contiguous bf16 vector of N entries")
     if tuple(out.shape) != (M, N):
         raise DeviceError(f"gemm: output is {tuple(out.shape)}, expected {(M, N)}")
+    # operand shapes per layout: a slip here would be an out-of-bounds device access
+    want_a, want_b = {NT: ((M, K), (N, K)), NN: ((M, K), (K, N)), TN: ((K, M), (K, N))}[layout]
+    if tuple(a.shape) != want_a or tuple(b.shape) != want_b:
+        raise DeviceError(
+            f"gemm: operands are {tuple(a.shape)} and {tuple(b.shape)}, layout {layout} with "
+            f"M, N, K = {M}, {N}, {K} needs {want_a} and {want_b}")
+    if M < 1 or N < 1 or K < 1:
+        raise DeviceError("gemm: empty problem")
+    for t in (a, b, out2, bias):
+        if t is not None and t.device != out.device:
+            raise DeviceError("gemm: operands live on different devices")
+    if out.device.type not in _DEVICE_TYPES:
+        raise DeviceError("gemm: device tensors are required")
+    # the epilogue stores whole 16-byte pieces: columns N .. round8(N) - 1 of every row are
+    # written too, so they must belong to this matrix's rows (padding), not to a neighbour
+    n8 = (N + 7) // 8 * 8
+    for t in (out, out2):
+        if t is None or n8 == N or t.shape[0] == 0:
+            continue
+        col0 = t.storage_offset() % t.stride(0) if t.stride(0) else 0
+        if t.stride(0) < n8 or col0 != 0:
+            raise DeviceError(
+                f"gemm: N = {N} is not a multiple of 8: the output must start at column 0 of "
+                f"rows at least {n8} long (the columns up to {n8} are written as padding), "
+                "not be a column slice inside a wider matrix")
     lib = library.hip_lib()
     fn = lib.nf_gemm_bf16
     if not getattr(fn, "_declared", False):

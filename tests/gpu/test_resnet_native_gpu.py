@@ -148,7 +148,7 @@ def test_batched_gemm_equals_a_loop_of_single_gemms(layout, M, N, K):
     b = torch.randn(batch, b_shape[0] * b_shape[1] + pad, device=DEV).to(BF)
     c = torch.zeros(batch, M * N + pad, device=DEV, dtype=BF)
     slabs = torch.empty(max(go.gemm_slab_floats(M, N, K, layout, batch), 1), device=DEV)
-    go.gemm_batched(layout, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, a_shape[1],
+    go.gemm_batched(layout, a, b, c, M, N, K, a_shape[1],
                     b_shape[1], N, batch, a.stride(0), b.stride(0), c.stride(0), slabs,
                     go._stream(c))
     for i in range(batch):

@@ -41,15 +41,15 @@ for name, (N, K) in shapes.items():
             gemm_ops.linear_wgrad(dy[g][:, :N], x[g], dw[g])
 
     def batched():
-        go.gemm_batched(0, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, LD, G,
+        go.gemm_batched(0, x, w, y, M, N, K, K, K, LD, G,
                         M * K, N * K, M * LD, slabs, go._stream(y))
 
     def batched_d():
-        go.gemm_batched(1, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, K, N, LD, K, K, G,
+        go.gemm_batched(1, dy, w, dx, M, K, N, LD, K, K, G,
                         M * LD, N * K, M * K, slabs, go._stream(y))
 
     def batched_w():
-        go.gemm_batched(2, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, M, LD, K, K, G,
+        go.gemm_batched(2, dy, x, dw, N, K, M, LD, K, K, G,
                         M * LD, M * K, N * K, slabs, go._stream(y))
 
     row = {}
