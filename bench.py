@@ -302,7 +302,7 @@ def main() -> int:
     engine.close()
     if scratch is not None:
         shutil.rmtree(scratch, ignore_errors=True)
-    comm.finish(0)  # multi-process: leaves here, past the libraries' exit handlers
+    comm.finish(0)  # the process group is destroyed before the interpreter shuts down
     return 0
 
 

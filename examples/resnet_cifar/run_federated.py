@@ -51,7 +51,7 @@ def main() -> None:
     if comm.is_root:
         print(json.dumps({"eval": engine.evaluate()}))
     engine.close()
-    comm.finish()  # under a launcher (several ranks) the process leaves here
+    comm.finish()  # the process group is destroyed before the interpreter shuts down
 
 
 if __name__ == "__main__":

@@ -111,7 +111,7 @@ def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_c
     if comm.is_root:
         click.echo(json.dumps({"eval": engine.evaluate()}))
     engine.close()
-    comm.finish(0)  # several ranks: leaves here, past the libraries' exit handlers
+    comm.finish(0)  # the process group is destroyed before the interpreter shuts down
 
 
 @main.command(context_settings={"ignore_unknown_options": True})
