@@ -421,7 +421,25 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
         const int col = n0 + wcol + j * 32 + n;
         bias[j] = (g.bias != nullptr && col < g.N) ? bf2f(g.bias[col]) : 0.f;
     }
+    // The tile is rounded to bf16 first (two values per register): half the registers of
+    // the fp32 accumulators stay alive through the staging below - with the 128
+    // accumulator registers of the 256 x 256 tile the staging code's temporaries used to
+    // push 45 registers into scratch.
+    unsigned pk[RM][RN][8];
 #pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bf16x2 two = {f2bf(acc[i][j][2 * r] + bias[j]), f2bf(acc[i][j][2 * r + 1] + bias[j])};
+                unsigned word = __builtin_bit_cast(unsigned, two);
+                // (an empty asm: the optimiser may not split the pair into two registers again)
+                asm volatile("" : "+v"(word));
+                pk[i][j][r] = word;
+            }
+    // (one copy of the staging code for both outputs: `which` is a run-time value)
+#pragma unroll 1
     for (int which = 0; which < 2; ++which) {
         if (which == 1 && g.C2 == nullptr) break;
 #pragma unroll
@@ -433,12 +451,22 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < RN; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float v = acc[i][j][r] + bias[j];
-                            if (which == 1) v = gelu_tanh(bf2f(f2bf(v)));
-                            const int row = wrow % kOutRows + i * 32 + acc_row(r, lane);
-                            *reinterpret_cast<bf16*>(smem + row * G::OUT_PITCH +
-                                                     (wcol + j * 32 + n) * 2) = f2bf(v);
+                        for (int r = 0; r < 16; r += 2) {
+                            unsigned word = pk[i][j][r >> 1];
+                            // (the halves are taken apart here, inside the part's branch, and
+                            // not hoisted above it into 128 registers)
+                            asm volatile("" : "+v"(word));
+                            bf16x2 two = __builtin_bit_cast(bf16x2, word);
+                            if (which == 1) {
+                                two[0] = f2bf(gelu_tanh(bf2f(two[0])));
+                                two[1] = f2bf(gelu_tanh(bf2f(two[1])));
+                            }
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int row = wrow % kOutRows + i * 32 + acc_row(r + h, lane);
+                                *reinterpret_cast<bf16*>(smem + row * G::OUT_PITCH +
+                                                         (wcol + j * 32 + n) * 2) = two[h];
+                            }
                         }
             }
             __syncthreads();

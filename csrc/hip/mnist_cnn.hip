@@ -1428,6 +1428,15 @@ __device__ __forceinline__ float sum_slabs(const float* p, int count, long strid
     const int lo = (count * wave) >> 2, hi = (count * (wave + 1)) >> 2;
     float s0 = 0.f, s1 = 0.f;
     int i = lo;
+    // 16 loads in flight per lane (the kernel is a few round trips to memory, nothing else);
+    // the order of the additions is that of the two-at-a-time loop below
+    for (; i + 15 < hi; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[(i + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) { s0 += v[k]; s1 += v[k + 1]; }
+    }
 #pragma unroll 4
     for (; i + 1 < hi; i += 2) {
         s0 += p[(i + 0) * stride];

@@ -88,10 +88,18 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1)
         return int(_FORCED_GEO)
     ksteps = (K + 63) // 64
     t256 = (-(-M // 256)) * (-(-N // 256)) * batch
-    if t256 >= 224 and ksteps >= 32 and min(M, N) >= 2048:
-        return GEO_256        # enough 256 x 256 tiles for every CU, a long K loop, both sides wide
+    if t256 >= 192 and min(M, N) >= 2048 and not (layout == NT and N % 192 == 0 and t256 < 256):
+        # both sides wide and 256 x 256 tiles for three quarters of the CUs or more: the big
+        # tile reads the fewest operand bytes per MFMA (4096 x 3072 x 768: 29.8 us against
+        # 33.7 us; the LM head's forward 371 us against 442 us).  A k-contiguous output of
+        # 192-column multiples just at that size is left to the 128 x 192 tile below.
+        return GEO_256
+    if t256 >= 48 and ksteps >= 256 and min(M, N) >= 512:
+        # a very long reduction (the LM head's input gradient, K = 50257, cut along K):
+        # 389 us against 472 us
+        return GEO_256
     if layout == TN and t256 >= 224 and ksteps >= 32 and max(M, N) >= 16384 and min(M, N) >= 512:
-        return GEO_256        # the LM head's weight gradient: one very long side (344 vs 401 us)
+        return GEO_256        # the LM head's weight gradient: one very long side (377 vs 408 us)
     if t256 >= 1024 and layout == NT:
         return GEO_256x128    # very wide outputs with a short K loop (the LM head)
     if layout == NT and N % 192 == 0:

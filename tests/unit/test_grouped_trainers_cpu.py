@@ -60,4 +60,4 @@ def test_batched_gemm_heuristics_count_the_tiles_of_all_problems():
     # geometry: the tile count that selects the wide tiles is the batch's
     one = gemm_ops.choose_geometry(4096, 2304, 768, gemm_ops.NT)
     many = gemm_ops.choose_geometry(4096, 2304, 768, gemm_ops.NT, batch=8)
-    assert one == gemm_ops.GEO_128x192 and many == gemm_ops.GEO_256x128
+    assert one == gemm_ops.GEO_128x192 and many == gemm_ops.GEO_256
