@@ -61,6 +61,8 @@ def info() -> None:
 @click.option("--dp-clip", default=1.0)
 @click.option("--backend", type=click.Choice(["auto", "native", "torch"]), default="auto")
 @click.option("--base-dir", default=None, type=click.Path(), help="write models/ and metrics/ here")
+@click.option("--data-dir", default="./data", type=click.Path(),
+              help="where --dataset mnist / cifar10 look for their files (IDX files; CIFAR-10 binary batches)")
 @click.option("--seq-len", default=1024, help="sequence length of token datasets")
 @click.option("--min-clients", default=1, help="quorum: valid updates needed to close a round")
 @click.option("--max-update-norm", default=0.0, help="reject updates farther than this from the global model")
@@ -73,7 +75,7 @@ def info() -> None:
               help="blind client rows with pairwise masks before the reduce")
 @click.option("--sign-updates", is_flag=True, help="clients sign their updates (RSA-PSS), verified before aggregation")
 def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_client, lr,
-        partition, alpha, dp_noise, dp_clip, backend, base_dir, seq_len, min_clients,
+        partition, alpha, dp_noise, dp_clip, backend, base_dir, data_dir, seq_len, min_clients,
         max_update_norm, checkpoint_rounds, resume, phases, zscore, secure_agg,
         sign_updates) -> None:
     """Federated rounds on the device plane (launch under torch.distributed.run for multi-GPU)."""
@@ -81,7 +83,7 @@ def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_c
     from nanofed_amd.parallel import Communicator
 
     default_ds = {"mnist_cnn": "synthetic_mnist", "mnist_mlp": "synthetic_mnist",
-                  "resnet18": "synthetic_cifar10", "gpt2_125m": "synthetic_tokens"}
+                  "resnet18": "synthetic_cifar10_hard", "gpt2_125m": "synthetic_tokens"}
     cfg = EngineConfig(
         model=model, dataset=dataset or default_ds.get(model, "synthetic_mnist"),
         num_clients=clients, num_rounds=rounds, local_epochs=local_epochs,
@@ -89,7 +91,7 @@ def run(model, dataset, clients, rounds, local_epochs, batch_size, samples_per_c
         partition=partition, dirichlet_alpha=alpha, backend=backend, seq_len=seq_len,
         min_clients=min_clients, max_update_norm=max_update_norm,
         checkpoint_rounds=checkpoint_rounds, zscore_threshold=zscore, secure_agg=secure_agg,
-        sign_updates=sign_updates,
+        sign_updates=sign_updates, data_dir=str(data_dir),
         dp=DPConfig(max_gradient_norm=dp_clip, noise_multiplier=dp_noise) if dp_noise > 0 else None,
     )
     comm = Communicator.from_env()

@@ -1,3 +1,10 @@
+from .cifar import (
+    CIFAR10_MEAN,
+    CIFAR10_STD,
+    load_cifar10_arrays,
+    load_cifar10_data,
+    write_cifar10_batch,
+)
 from .mnist import load_mnist_arrays, load_mnist_data, normalize_mnist, read_idx
 from .partition import (
     dirichlet_partition,
@@ -7,6 +14,7 @@ from .partition import (
 )
 from .synthetic import (
     synthetic_cifar10,
+    synthetic_cifar10_hard,
     synthetic_images,
     synthetic_mnist,
     synthetic_mnist_hard,
@@ -26,5 +34,11 @@ __all__ = [
     "synthetic_mnist",
     "synthetic_mnist_hard",
     "synthetic_cifar10",
+    "synthetic_cifar10_hard",
+    "load_cifar10_arrays",
+    "load_cifar10_data",
+    "write_cifar10_batch",
+    "CIFAR10_MEAN",
+    "CIFAR10_STD",
     "synthetic_tokens",
 ]

@@ -40,7 +40,7 @@ class EngineConfig:
     learning_rate: float = 0.1
     weight_decay: float = 0.0
     # data
-    dataset: str = "synthetic_mnist"  # synthetic_mnist | synthetic_mnist_hard | synthetic_cifar10 | synthetic_tokens | mnist
+    dataset: str = "synthetic_mnist"  # synthetic_mnist[_hard] | mnist | synthetic_cifar10[_hard] | cifar10 | synthetic_tokens
     samples_per_client: int | Sequence[int] = 7500
     partition: str = "iid"  # iid | dirichlet
     dirichlet_alpha: float = 0.1

@@ -24,10 +24,12 @@ from nanofed_amd.data import (
     iid_partition,
     sized_partition,
     synthetic_cifar10,
+    synthetic_cifar10_hard,
     synthetic_mnist,
     synthetic_mnist_hard,
     synthetic_tokens,
 )
+from nanofed_amd.data.cifar import CIFAR10_MEAN, CIFAR10_STD, load_cifar10_arrays
 from nanofed_amd.data.mnist import MNIST_MEAN, MNIST_STD, load_mnist_arrays
 
 from .config import EngineConfig
@@ -47,6 +49,10 @@ class FederatedData:
     std: tuple[float, ...] = (1.0,)
 
 
+IMAGE_DATASETS = ("synthetic_mnist", "synthetic_mnist_hard", "mnist", "synthetic_cifar10",
+                  "synthetic_cifar10_hard", "cifar10")
+
+
 def _sizes(cfg: EngineConfig) -> list[int]:
     spc = cfg.samples_per_client
     if isinstance(spc, int):
@@ -63,7 +69,7 @@ def build_federated_data(cfg: EngineConfig) -> FederatedData:
     builds the same object and keeps only its clients' shards on its GPU."""
     sizes = _sizes(cfg)
     total = sum(sizes)
-    if cfg.dataset in ("synthetic_mnist", "synthetic_mnist_hard", "mnist", "synthetic_cifar10"):
+    if cfg.dataset in IMAGE_DATASETS:
         if cfg.dataset in ("synthetic_mnist", "synthetic_mnist_hard"):
             make = synthetic_mnist if cfg.dataset == "synthetic_mnist" else synthetic_mnist_hard
             x, y = make(total, seed=cfg.seed)
@@ -74,10 +80,17 @@ def build_federated_data(cfg: EngineConfig) -> FederatedData:
             ex, ey = load_mnist_arrays(cfg.data_dir, train=False, synthetic_fallback=True)
             ex, ey = ex[: cfg.eval_samples], ey[: cfg.eval_samples]
             mean, std = (MNIST_MEAN,), (MNIST_STD,)
+        elif cfg.dataset == "cifar10":
+            # the binary batches under cfg.data_dir (never the pickled version)
+            x, y = load_cifar10_arrays(cfg.data_dir, train=True, synthetic_fallback=True)
+            ex, ey = load_cifar10_arrays(cfg.data_dir, train=False, synthetic_fallback=True)
+            ex, ey = ex[: cfg.eval_samples], ey[: cfg.eval_samples]
+            mean, std = CIFAR10_MEAN, CIFAR10_STD
         else:
-            x, y = synthetic_cifar10(total, seed=cfg.seed)
-            ex, ey = synthetic_cifar10(cfg.eval_samples, seed=cfg.seed + 1)
-            mean, std = (0.4914, 0.4822, 0.4465), (0.2470, 0.2435, 0.2616)
+            make = synthetic_cifar10 if cfg.dataset == "synthetic_cifar10" else synthetic_cifar10_hard
+            x, y = make(total, seed=cfg.seed)
+            ex, ey = make(cfg.eval_samples, seed=cfg.seed + 1)
+            mean, std = CIFAR10_MEAN, CIFAR10_STD
         if total > len(x):
             raise ValueError(
                 f"clients ask for {total} samples, dataset has {len(x)}"

@@ -274,6 +274,8 @@ class FederatedEngine:
         torch.manual_seed(cfg.seed)  # identical initial model on every rank
         self._model_factory = lambda: build_model(cfg.model, **cfg.model_kwargs)
         self._host_model = self._model_factory()
+        # (the data first: which trainer can run depends on its shape, not on its name)
+        self.data = data or build_federated_data(cfg)
         self.backend = self._resolve_backend()
         if self.backend == "native" and cfg.model == "mnist_cnn":
             from .mnist_native import make_layout
@@ -289,7 +291,6 @@ class FederatedEngine:
         self.global_arena.load_state_dict(self._host_model.state_dict())
         self.comm.broadcast(self.global_arena.data, src=0)
 
-        self.data = data or build_federated_data(cfg)
         self.shards = DeviceShards(
             self.data, self.client_ids, self.device, cfg.batch_size, cfg.seed,
             cfg.drop_last,
@@ -420,7 +421,7 @@ class FederatedEngine:
         if cfg.model == "resnet18" and on_gpu:
             from .resnet_native import supports as resnet_supports
 
-            resnet_ok = resnet_supports(cfg, self._host_model, self.device)
+            resnet_ok = resnet_supports(cfg, self._host_model, self.device, self.data)
         return "native" if (mnist_ok or gpt2_ok or resnet_ok) else "torch"
 
     def _setup_persistence(self) -> None:

@@ -79,18 +79,31 @@ class _Block:
     us: _Unit | None
 
 
-def supports(cfg: EngineConfig, model: nn.Module, device: torch.device) -> bool:
-    """The grouped kernels cover the CIFAR ResNet-18 of this package (width 64, 32x32
-    inputs) in bf16 without DP, batch sizes that are multiples of 8."""
+def supports(cfg: EngineConfig, model: nn.Module, device: torch.device, data=None) -> bool:
+    """The grouped kernels cover the CIFAR ResNet-18 of this package (width 64) in bf16
+    without DP, batch sizes that are multiples of 8, on any image set of the CIFAR shape:
+    uint8 ``[N, 3, 32, 32]`` with one mean and one positive std per channel (``data``: the
+    engine's ``FederatedData``; what is tested is the data, not the dataset's name)."""
     if os.environ.get("NANOFED_RESNET_NATIVE", "1") == "0":
         return False
     if device.type != "cuda" or cfg.dtype != "bf16" or cfg.dp is not None:
         return False
     if not isinstance(model, ResNet18) or model.fc.in_features != 512 or model.fc.out_features > 16:
         return False
-    if cfg.dataset != "synthetic_cifar10" or not gemm_ops.enabled(device):
+    if not gemm_ops.enabled(device) or not cifar_shaped(data):
         return False
     return cfg.batch_size % 8 == 0 and 8 <= cfg.batch_size <= 512
+
+
+def cifar_shaped(data) -> bool:
+    if data is None or getattr(data, "kind", None) != "image":
+        return False
+    x = data.inputs
+    if x.dtype != torch.uint8 or x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
+        return False
+    if data.labels is None or len(data.mean) != 3 or len(data.std) != 3:
+        return False
+    return all(float(s) > 0.0 for s in data.std)
 
 
 class ResNetNativeTrainer(TorchGroupTrainer):

@@ -247,6 +247,33 @@ def test_auto_backend_picks_the_grouped_trainer():
     assert isinstance(eng.trainer, ResNetNativeTrainer)
 
 
+def test_any_cifar_shaped_image_set_gets_the_grouped_trainer(tmp_path):
+    """The data decide, not the dataset's name: CIFAR-10 binary batches on disk (fixture
+    files in the format) and the hard synthetic set both train on the grouped kernels."""
+    import numpy as np
+
+    from nanofed_amd.data import write_cifar10_batch
+    from nanofed_amd.data.cifar import names_of
+    from nanofed_amd.engine.resnet_native import ResNetNativeTrainer
+
+    rng = np.random.default_rng(0)
+    folder = tmp_path / "cifar-10-batches-bin"
+    folder.mkdir()
+    for name in names_of(True) + names_of(False):
+        y = rng.integers(0, 10, size=64)
+        x = (rng.integers(0, 96, size=(64, 3, 32, 32)) + 16 * y[:, None, None, None]).astype(np.uint8)
+        write_cifar10_batch(folder / name, x, y)
+    torch.cuda.set_device(0)
+    for kw in (dict(dataset="cifar10", data_dir=str(tmp_path)), dict(dataset="synthetic_cifar10_hard")):
+        cfg = EngineConfig(model="resnet18", num_clients=2, samples_per_client=64, batch_size=32,
+                           local_epochs=1, eval_samples=64, learning_rate=0.05, seed=5, **kw)
+        eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
+        assert isinstance(eng.trainer, ResNetNativeTrainer), kw
+        reps = eng.run(3)
+        assert all(r.status == "COMPLETED" for r in reps)
+        assert reps[-1].agg_metrics["loss"] < reps[0].agg_metrics["loss"]
+
+
 def test_gradients_of_a_batch_against_fp32_autograd_on_the_same_weights():
     from nanofed_amd.models import build_model
 
