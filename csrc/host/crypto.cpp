@@ -2,7 +2,9 @@
 //
 // A thin C ABI over OpenSSL 3 EVP: RSA key generation, RSA-OAEP(SHA-256,
 // MGF1-SHA-256) encryption of fixed-size chunks, RSA-PSS(SHA-256, maximum salt)
-// signatures, AES-256-GCM sealing and PBKDF2-HMAC-SHA-256.  Loaded from Python
+// signatures, AES-256-GCM sealing, PBKDF2-HMAC-SHA-256 and X25519 key agreement
+// (raw 32-byte keys; the shared secret is hashed with a caller-supplied context
+// into pair seeds for the blinding masks of secure aggregation).  Loaded from Python
 // with ctypes (nanofed_amd/crypto/backend.py).  Every function returns a
 // negative value on failure and never throws; no state is kept besides the
 // EVP_PKEY handles the caller owns.
@@ -214,6 +216,56 @@ int nf_pbkdf2_sha256(const uint8_t* pass, long passlen, const uint8_t* salt,
                              static_cast<int>(outlen), out) > 0
                ? 0
                : -1;
+}
+
+// X25519 key pair: 32 raw private and 32 raw public bytes.
+int nf_x25519_generate(uint8_t* priv32, uint8_t* pub32) {
+    EVP_PKEY* key = EVP_PKEY_Q_keygen(nullptr, nullptr, "X25519");
+    if (!key) return -1;
+    size_t n_priv = 32, n_pub = 32;
+    const bool ok = EVP_PKEY_get_raw_private_key(key, priv32, &n_priv) > 0 && n_priv == 32 &&
+                    EVP_PKEY_get_raw_public_key(key, pub32, &n_pub) > 0 && n_pub == 32;
+    EVP_PKEY_free(key);
+    return ok ? 0 : -2;
+}
+
+// Public half of a raw private key.
+int nf_x25519_public(const uint8_t* priv32, uint8_t* pub32) {
+    EVP_PKEY* key = EVP_PKEY_new_raw_private_key(EVP_PKEY_X25519, nullptr, priv32, 32);
+    if (!key) return -1;
+    size_t n_pub = 32;
+    const bool ok = EVP_PKEY_get_raw_public_key(key, pub32, &n_pub) > 0 && n_pub == 32;
+    EVP_PKEY_free(key);
+    return ok ? 0 : -2;
+}
+
+// out32 = SHA-256(X25519(priv, peer_pub) || context).  Fails (< 0) on a malformed or
+// low-order peer key (OpenSSL rejects an all-zero shared secret).
+int nf_x25519_derive(const uint8_t* priv32, const uint8_t* peer_pub32, const uint8_t* context,
+                     long context_len, uint8_t* out32) {
+    EVP_PKEY* mine = EVP_PKEY_new_raw_private_key(EVP_PKEY_X25519, nullptr, priv32, 32);
+    EVP_PKEY* peer = EVP_PKEY_new_raw_public_key(EVP_PKEY_X25519, nullptr, peer_pub32, 32);
+    int rc = -1;
+    uint8_t secret[32];
+    size_t n = sizeof(secret);
+    if (mine && peer) {
+        CtxGuard g(EVP_PKEY_CTX_new(mine, nullptr));
+        if (g.ctx && EVP_PKEY_derive_init(g.ctx) > 0 && EVP_PKEY_derive_set_peer(g.ctx, peer) > 0 &&
+            EVP_PKEY_derive(g.ctx, secret, &n) > 0 && n == 32) {
+            EVP_MD_CTX* md = EVP_MD_CTX_new();
+            unsigned int out_len = 0;
+            if (md && EVP_DigestInit_ex(md, EVP_sha256(), nullptr) > 0 &&
+                EVP_DigestUpdate(md, secret, 32) > 0 &&
+                EVP_DigestUpdate(md, context, static_cast<size_t>(context_len)) > 0 &&
+                EVP_DigestFinal_ex(md, out32, &out_len) > 0 && out_len == 32)
+                rc = 0;
+            if (md) EVP_MD_CTX_free(md);
+        }
+        OPENSSL_cleanse(secret, sizeof(secret));
+    }
+    if (mine) EVP_PKEY_free(mine);
+    if (peer) EVP_PKEY_free(peer);
+    return rc;
 }
 
 int nf_random_bytes(uint8_t* out, long len) {

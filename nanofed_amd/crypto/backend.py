@@ -1,7 +1,7 @@
 """ctypes bindings for the native crypto library (csrc/host/crypto.cpp).
 
 Provides the primitives the secure aggregators and the update signer need:
-``RSAKey`` (generate / public PEM / OAEP-SHA256 chunk encryption / PSS-SHA256
+``X25519Key`` (key agreement for pair seeds), ``RSAKey`` (generate / public PEM / OAEP-SHA256 chunk encryption / PSS-SHA256
 signatures), ``aesgcm_seal`` / ``aesgcm_open`` (AES-256-GCM, 12-byte nonce,
 16-byte tag appended) and ``pbkdf2_sha256``.  The library is built on first
 use if the shared object is missing and a compiler is available.
@@ -55,7 +55,40 @@ def _lib() -> ctypes.CDLL:
     lib.nf_pbkdf2_sha256.restype = c_int
     lib.nf_pbkdf2_sha256.argtypes = [
         c_char_p, c_long, c_char_p, c_long, c_int, c_char_p, c_long]
+    lib.nf_x25519_generate.argtypes = [c_char_p, c_char_p]
+    lib.nf_x25519_public.argtypes = [c_char_p, c_char_p]
+    lib.nf_x25519_derive.argtypes = [c_char_p, c_char_p, c_char_p, c_long, c_char_p]
     return lib
+
+
+class X25519Key:
+    """An X25519 key pair (RFC 7748).  ``public`` is what travels; ``derive`` turns a
+    peer's public key into 32 secret bytes both sides compute alike:
+    SHA-256(shared secret || context)."""
+
+    def __init__(self, private: bytes) -> None:
+        if len(private) != 32:
+            raise CryptoError("an X25519 private key is 32 bytes")
+        self._private = bytes(private)
+        pub = ctypes.create_string_buffer(32)
+        if _lib().nf_x25519_public(self._private, pub) != 0:
+            raise CryptoError("X25519 public key derivation failed")
+        self.public = pub.raw
+
+    @classmethod
+    def generate(cls) -> "X25519Key":
+        priv, pub = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        if _lib().nf_x25519_generate(priv, pub) != 0:
+            raise CryptoError("X25519 key generation failed")
+        return cls(priv.raw)
+
+    def derive(self, peer_public: bytes, context: bytes = b"") -> bytes:
+        if len(peer_public) != 32:
+            raise CryptoError("an X25519 public key is 32 bytes")
+        out = ctypes.create_string_buffer(32)
+        if _lib().nf_x25519_derive(self._private, bytes(peer_public), context, len(context), out) != 0:
+            raise CryptoError("X25519 agreement failed (malformed or low-order peer key)")
+        return out.raw
 
 
 class RSAKey:

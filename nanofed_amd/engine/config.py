@@ -97,6 +97,10 @@ class EngineConfig:
     # unmatched masks are removed on device); "none" reduces the plain rows
     secure_agg: str = "none"
     secure_mask_scale: float = 1.0
+    # Pair seeds come from X25519 agreement between the clients' key pairs.  None: fresh
+    # random keys per engine.  An integer derives the private keys from it - reproducible
+    # masks for tests and debugging, and no secrecy (who knows the number knows the keys).
+    secure_key_seed: int | None = None
     # signed updates (reference: SecurityManager.sign_update / verify_signature,
     # nanofed/server/validation.py:138-212): every client holds an RSA-2048 key and signs
     # (round, client id, tree digest of its arena row) with RSA-PSS; before aggregation the

@@ -330,7 +330,8 @@ class FederatedEngine:
         self._need_delta = cfg.max_update_norm > 0 or cfg.zscore_threshold > 0
         self._tail_graph: torch.cuda.CUDAGraph | None = None
         self._tail_rounds = 0
-        self._secure_seeds: torch.Tensor | None = None
+        self._own_seed_rows: torch.Tensor | None = None
+        self.secure_public_keys: list[bytes] = []
         self._shares: torch.Tensor | None = None
         if cfg.secure_agg == "pairwise":
             self._setup_secure_agg()
@@ -466,19 +467,50 @@ class FederatedEngine:
         self._recovery = None
 
     def _setup_secure_agg(self) -> None:
-        """Pair seeds of the blinding masks.  Stand-in for pairwise key agreement:
-        derived from the run seed so that every rank (and a test) computes the same
-        table; entry [i][j] = [j][i]."""
-        K = self.cfg.num_clients
+        """Pair seeds of the blinding masks, by key agreement: every client draws an X25519
+        key pair, the public halves travel in one all-gather, and client i derives the seed
+        it shares with peer j as SHA-256(X25519(sk_i, pk_j) || context) - the same 63 bits
+        on both sides, known to nobody else.  The aggregating side of this object keeps the
+        public keys only; a client's seeds stay in its own ``PeerMaskPlan`` and its row of
+        ``_own_seed_rows`` (from which a survivor reveals, after the reduce, the seeds it
+        shared with clients that dropped out - what the repair of their unmatched masks
+        needs; reference capability: nanofed/server/aggregator/secure.py:192-313)."""
+        from nanofed_amd.crypto.backend import X25519Key
+
+        cfg, K = self.cfg, self.cfg.num_clients
         if K < 2:
             raise DeviceError("pairwise secure aggregation needs at least two clients")
-        table = torch.zeros(K, K, dtype=torch.int64)
-        for i in range(K):
-            for j in range(i + 1, K):
-                digest = hashlib.sha256(f"nanofed|{self.cfg.seed}|{i}|{j}".encode()).digest()
-                table[i, j] = table[j, i] = int.from_bytes(digest[:8], "big") >> 1
-        self._secure_seed_table = table
-        self._secure_seeds = table.to(self.device)
+        keys: dict[int, X25519Key] = {}
+        for cid in self.client_ids:
+            if cfg.secure_key_seed is None:
+                keys[cid] = X25519Key.generate()
+            else:
+                keys[cid] = X25519Key(hashlib.sha256(
+                    f"nanofed-x25519|{cfg.secure_key_seed}|{cid}".encode()).digest())
+        mine = torch.zeros(self.max_local, 32, dtype=torch.uint8)
+        for k, cid in enumerate(self.client_ids):
+            mine[k] = torch.frombuffer(bytearray(keys[cid].public), dtype=torch.uint8)
+        gathered = self.comm.allgather(mine.to(self.device)).cpu()  # [W, max_local, 32]
+        public: list[bytes] = []
+        for w, count in enumerate(self._rank_counts):
+            public += [bytes(gathered[w, i].tolist()) for i in range(count)]
+        if len(set(public)) != K:
+            raise DeviceError("secure aggregation: two clients announced the same public key")
+        self.secure_public_keys = public
+        own = torch.zeros(K, K, dtype=torch.int64)
+        self._mask_plans: list[ops.PeerMaskPlan] = []
+        for cid in self.client_ids:
+            peers = [j for j in range(K) if j != cid]
+            seeds = []
+            for j in peers:
+                context = b"nanofed-pair-mask|%d|%d" % (min(cid, j), max(cid, j))
+                digest = keys[cid].derive(public[j], context)
+                seeds.append(int.from_bytes(digest[:8], "big") >> 1)
+                own[cid, j] = seeds[-1]
+            self._mask_plans.append(
+                ops.PeerMaskPlan(seeds, [1.0 if cid < j else -1.0 for j in peers]))
+        # (the private keys are dropped here: the seeds are all a client needs afterwards)
+        self._own_seed_rows = own.to(self.device)
         # a client's share of the total sample count is public metadata (the
         # counts travel in the clear in the reference too, client.py:180-189)
         sizes = torch.tensor([float(len(s)) for s in self.data.shards], dtype=torch.float32)
@@ -708,6 +740,9 @@ class FederatedEngine:
         graphable = (
             self.cfg.tail_graph and self.device.type == "cuda" and not self.comm.collective
             and not eager and local is not None
+            # (the blinding masks take the round number as their stream offset: a kernel
+            # argument, frozen in a recorded graph)
+            and self.cfg.secure_agg == "none"
         )
         if graphable:
             if self._tail_graph is None and self._tail_rounds >= 1:
@@ -852,17 +887,20 @@ class FederatedEngine:
         cfg, comm = self.cfg, self.comm
         scale = cfg.secure_mask_scale
         offset = self.round_id
-        table = self._secure_seed_table
         for k, cid in enumerate(self.client_ids):
-            peers = [j for j in range(self._K) if j != cid]
-            ops.pairwise_mask_(
-                self.pool[k].data, [int(table[cid, j]) for j in peers],
-                [1.0 if cid < j else -1.0 for j in peers], scale,
-                prescale=self._shares_host[cid], offset=offset,
-            )
+            ops.pairwise_mask_(self.pool[k].data, self._mask_plans[k], None, scale,
+                               prescale=self._shares_host[cid], offset=offset)
         present = (records[:, M_VALID] > 0).to(torch.float32)
         self._reduce_rows(present, lo, G)
-        ops.pairwise_repair_(self._partial, present, self._secure_seeds, scale, offset=offset)
+        # The survivors reveal the seeds they shared with the clients that are missing:
+        # entry (i, j) of the table is filled by the rank of a present client i for a
+        # missing client j, and nothing else is - decided on the device, no host round trip.
+        here = present > 0
+        reveal = self._own_seed_rows * (here[:, None] & ~here[None, :]).to(torch.int64)
+        reveal = reveal + reveal.t()
+        if comm.collective:
+            comm.allreduce_sum(reveal.view(-1), algo="allreduce")
+        ops.pairwise_repair_(self._partial, present, reveal.contiguous(), scale, offset=offset)
         mass = (present * self._shares).sum().clamp(min=1e-30)
         self._partial.div_(mass)
 

@@ -14,6 +14,7 @@ from .arena_ops import (
     MODE_UNIFORM,
     clip_noise,
     l2_norm,
+    PeerMaskPlan,
     pairwise_mask_,
     pairwise_repair_,
     philox_fill,
@@ -56,6 +57,7 @@ __all__ = [
     "hip_lib",
     "l2_norm",
     "mask_add_",
+    "PeerMaskPlan",
     "pairwise_mask_",
     "pairwise_repair_",
     "philox_fill",

@@ -538,37 +538,57 @@ def select_copy(dst: torch.Tensor, src: torch.Tensor, flag: torch.Tensor) -> tor
     return dst
 
 
+class PeerMaskPlan:
+    """A client's pair seeds and signs, marshalled once for the launcher: the per-round
+    call then costs one launch per ``nf_max_peers`` peers and no Python loop over them."""
+
+    def __init__(self, seeds: Sequence[int], signs: Sequence[float]) -> None:
+        if len(seeds) != len(signs):
+            raise DeviceError("PeerMaskPlan: one sign per seed is required")
+        self.seeds = [int(s) for s in seeds]
+        self.signs = [float(v) for v in signs]
+        self._chunks: list[tuple] | None = None
+
+    def chunks(self) -> list[tuple]:
+        if self._chunks is None:
+            cap = int(library.hip_lib().nf_max_peers())
+            self._chunks = []
+            for lo in range(0, max(len(self.seeds), 1), cap):
+                chunk, sg = self.seeds[lo : lo + cap], self.signs[lo : lo + cap]
+                s_arr = (c_ulonglong * max(len(chunk), 1))(*[s & (2**64 - 1) for s in chunk])
+                f_arr = (c_float * max(len(chunk), 1))(*sg)
+                self._chunks.append((s_arr, f_arr, len(chunk)))
+        return self._chunks
+
+
 def pairwise_mask_(
     row: torch.Tensor,
-    seeds: Sequence[int],
-    signs: Sequence[float],
+    seeds: "Sequence[int] | PeerMaskPlan",
+    signs: Sequence[float] | None,
     scale: float,
     prescale: float = 1.0,
     offset: int = 0,
 ) -> torch.Tensor:
     """``row = prescale * row + sum_p signs[p] * scale * U_p`` where ``U_p`` is the
     symmetric-uniform Philox stream of ``seeds[p]`` (what ``mask_add_`` draws): a
-    client's blinding against all its peers in one pass."""
-    if row.dim() != 1 or len(seeds) != len(signs):
-        raise DeviceError("pairwise_mask_: a flat row and one sign per seed are required")
+    client's blinding against all its peers in one pass.  ``seeds`` may be a
+    ``PeerMaskPlan`` (then ``signs`` is ignored)."""
+    plan = seeds if isinstance(seeds, PeerMaskPlan) else PeerMaskPlan(seeds, signs or [])
+    if row.dim() != 1:
+        raise DeviceError("pairwise_mask_: a flat row is required")
     if row.device.type != "cuda":
         row.mul_(prescale)
-        for seed, sign in zip(seeds, signs):
+        for seed, sign in zip(plan.seeds, plan.signs):
             philox_fill(row, seed, offset, MODE_SYM_UNIFORM, scale=sign * scale, accumulate=True)
         return row
     library.require_flat_f32(row, "pairwise_mask_ row")
     lib = library.hip_lib()
-    cap = int(lib.nf_max_peers())
     first = True
-    for lo in range(0, max(len(seeds), 1), cap):
-        chunk = list(seeds[lo : lo + cap])
-        sg = list(signs[lo : lo + cap])
-        s_arr = (c_ulonglong * max(len(chunk), 1))(*[s & (2**64 - 1) for s in chunk])
-        f_arr = (c_float * max(len(chunk), 1))(*sg)
+    for s_arr, f_arr, count in plan.chunks():
         library.check(
             lib.nf_pairwise_mask(
                 _ptr(row), c_long(row.numel()), c_float(prescale if first else 1.0), s_arr,
-                f_arr, c_int(len(chunk)), c_float(scale), c_ulonglong(offset & (2**64 - 1)),
+                f_arr, c_int(count), c_float(scale), c_ulonglong(offset & (2**64 - 1)),
                 library.stream_ptr(row.device),
             ),
             "nf_pairwise_mask",

@@ -58,6 +58,36 @@ def test_pairwise_masked_round_equals_the_plain_round(dropped):
     assert min(diffs) > 0.1
 
 
+def test_pair_seeds_come_from_key_agreement_and_stay_with_the_clients():
+    """Every client announces an X25519 public key; a pair's seed is what both ends derive
+    from their own private key and the other's public key.  The engine object keeps the
+    public keys and, per local client, that client's seeds - no table of all pairs."""
+    from nanofed_amd.crypto.backend import X25519Key
+
+    eng = FederatedEngine(cfg(num_clients=4, secure_agg="pairwise"), comm=Communicator())
+    assert len(set(eng.secure_public_keys)) == 4 and all(len(k) == 32 for k in eng.secure_public_keys)
+    assert not hasattr(eng, "_secure_seed_table") and not hasattr(eng, "_secure_seeds")
+    rows = eng._own_seed_rows
+    assert torch.equal(rows, rows.t()) and int(rows.diagonal().abs().sum()) == 0
+    assert len({int(v) for v in rows[rows > 0]}) == 6  # one seed per pair, all different
+    # fresh keys per engine: another engine of the same configuration shares no seed
+    other = FederatedEngine(cfg(num_clients=4, secure_agg="pairwise"), comm=Communicator())
+    assert set(other.secure_public_keys).isdisjoint(eng.secure_public_keys)
+    # secure_key_seed: reproducible keys (tests, debugging)
+    a = FederatedEngine(cfg(num_clients=4, secure_agg="pairwise", secure_key_seed=7), comm=Communicator())
+    b = FederatedEngine(cfg(num_clients=4, secure_agg="pairwise", secure_key_seed=7), comm=Communicator())
+    assert a.secure_public_keys == b.secure_public_keys and torch.equal(a._own_seed_rows, b._own_seed_rows)
+    # the seed of pair (1, 2) is derivable from client 1's private key and 2's public key
+    import hashlib
+
+    sk1 = X25519Key(hashlib.sha256(b"nanofed-x25519|7|1").digest())
+    digest = sk1.derive(a.secure_public_keys[2], b"nanofed-pair-mask|1|2")
+    assert int(a._own_seed_rows[1, 2]) == int.from_bytes(digest[:8], "big") >> 1
+    a.run_round()
+    b.run_round()
+    assert torch.equal(a.global_arena.data, b.global_arena.data)
+
+
 def test_unknown_secure_mode_is_rejected():
     from nanofed_amd.core.exceptions import DeviceError
 

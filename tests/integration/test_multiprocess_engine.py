@@ -215,6 +215,22 @@ def test_library_reduces_agree_with_the_ordered_one_to_rounding(tmp_path, algo, 
     torch.testing.assert_close(dist["flat"], single_process_run["flat"], rtol=1e-5, atol=1e-6)
 
 
+def test_masked_rounds_on_three_ranks_with_dropouts_equal_the_plain_rounds(tmp_path):
+    """Pairwise masking across processes: the public keys travel in an all-gather, every
+    rank derives the seeds of its own clients only, and after the reduce the ranks of the
+    surviving clients reveal (one small all-reduce) the seeds they shared with the two
+    clients that dropped out of round 0.  The model equals the unmasked run to rounding."""
+    faults = dict(drop={0: {1, 6}})
+    plain = torch.load(_run_ok(tmp_path, 3, BASE_CFG, faults=faults, rounds=2, name="plain"),
+                       weights_only=False)
+    masked = torch.load(
+        _run_ok(tmp_path, 3, dict(BASE_CFG, secure_agg="pairwise"), faults=faults, rounds=2,
+                name="masked"), weights_only=False)
+    assert masked["status"] == plain["status"] == ["COMPLETED"] * 2
+    torch.testing.assert_close(masked["flat"], plain["flat"], rtol=0, atol=2e-5)
+    assert masked["weights"] == pytest.approx(plain["weights"])
+
+
 def test_a_failure_on_one_rank_only_is_agreed_on_and_recovered_by_all(tmp_path, single_process_run):
     cfg = dict(BASE_CFG, checkpoint_rounds=True)
     # only rank 1 raises, in the middle of round 1; rank 0 finishes its training
