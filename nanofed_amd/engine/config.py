@@ -97,6 +97,10 @@ class EngineConfig:
     # unmatched masks are removed on device); "none" reduces the plain rows
     secure_agg: str = "none"
     secure_mask_scale: float = 1.0
+    # Mixed rounds: this many extra arena rows take updates that clients outside the
+    # engine submitted for the round (FederatedEngine.submit_external; DeviceCoordinator
+    # fills them from its server) - same screening, same weighted sum, weight n_k.
+    external_slots: int = 0
     # Pair seeds come from X25519 agreement between the clients' key pairs.  None: fresh
     # random keys per engine.  An integer derives the private keys from it - reproducible
     # masks for tests and debugging, and no secrecy (who knows the number knows the keys).

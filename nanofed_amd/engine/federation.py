@@ -301,6 +301,11 @@ class FederatedEngine:
         K, W = cfg.num_clients, self.comm.world_size
         f32 = dict(dtype=torch.float32, device=self.device)
         self._K = K
+        # rows of the round: the K simulated clients, then the slots of outside clients
+        E = int(cfg.external_slots)
+        if E < 0 or (E and cfg.secure_agg != "none"):
+            raise DeviceError("external_slots must be >= 0 and cannot be combined with secure_agg")
+        self._E, self._KT = E, K + E
         # the reduced model, in a buffer long enough for the sliced collectives to work
         # on in place (whole slices of a multiple of 64 elements per rank)
         self._partial_full = torch.zeros(self.comm.padded_numel(self.layout.numel), **f32)
@@ -311,12 +316,21 @@ class FederatedEngine:
             raise DeviceError(f"unknown reduce_algo {cfg.reduce_algo!r}")
         # per-client records of this rank + one control row [failed flag, ...]
         self._local_records = torch.zeros(self.max_local + 1, METRIC_COLUMNS, **f32)
-        self._records = torch.zeros(K, METRIC_COLUMNS, **f32)
-        self._weights = torch.zeros(K, **f32)
+        self._records = torch.zeros(K + E, METRIC_COLUMNS, **f32)
+        self._weights = torch.zeros(K + E, **f32)
+        self._ext_full: torch.Tensor | None = None
+        if E:
+            # [E, padded numel] so that the sliced reduce can cut them like the arena
+            self._ext_full = torch.zeros(E, self.comm.padded_numel(self.layout.numel), **f32)
+            self._ext_rows = self._ext_full[:, : self.layout.numel]
+            self._ext_records = torch.zeros(E, METRIC_COLUMNS, **f32)
+            self._ext_stage = ParameterArena(self.layout, "cpu")
+            self._ext_pending: dict[int, tuple[torch.Tensor, list[float]]] = {}
+        self._ext_names = [f"external_{e}" for e in range(E)]
         self._flags = torch.zeros(4, **f32)
         self._control = torch.zeros(W, **f32)
         # everything the host reads at the end of a round, in one buffer
-        self._host_pack = torch.zeros(K * METRIC_COLUMNS + 4 + W, **f32)
+        self._host_pack = torch.zeros((K + E) * METRIC_COLUMNS + 4 + W, **f32)
         # the next round's broadcast and local training, queued behind this round's tail
         # before the host looks at this round's outcome: (round id, metrics tensor)
         self._prelaunched: tuple[int, torch.Tensor] | None = None
@@ -517,6 +531,52 @@ class FederatedEngine:
         self._shares_host = (sizes / sizes.sum().clamp(min=1.0)).tolist()
         self._shares = torch.tensor(self._shares_host, dtype=torch.float32).to(self.device)
 
+    # -- mixed rounds ---------------------------------------------------------------------
+    def submit_external(self, slot: int, state, num_samples: float,
+                        metrics: dict | None = None, client_id: str | None = None) -> None:
+        """Hand in the update of a client that trains outside this engine, for the round
+        that runs next (reference: a round is made of the updates that were POSTed,
+        nanofed/orchestration/coordinator.py:205-245,307-322).  ``state`` is a
+        ``state_dict`` of the model or a flat tensor in arena order; the update becomes row
+        ``K + slot`` of the round: screened like the resident clients' rows (finite values,
+        norm bound, z-score), weighted by ``num_samples``, added in the same fused sum.
+        With several ranks only rank 0 takes submissions; it broadcasts them in the round.
+        A slot nobody filled for a round takes no part in it."""
+        if not 0 <= slot < self._E:
+            raise DeviceError(f"external slot {slot} out of range (external_slots={self._E})")
+        if not self.comm.is_root:
+            raise DeviceError("external updates are submitted on rank 0")
+        if isinstance(state, torch.Tensor):
+            if state.numel() != self.layout.numel:
+                raise DeviceError("a flat external update must have the arena's length")
+            flat = state.detach().reshape(-1).to("cpu", torch.float32).clone()
+        else:
+            self._ext_stage.load_state_dict(state)
+            flat = self._ext_stage.data.clone()
+        m = metrics or {}
+        record = [0.0] * METRIC_COLUMNS
+        record[M_SAMPLES] = float(num_samples)
+        record[M_LOSS] = float(m.get("loss", 0.0))
+        record[M_ACC] = float(m.get("accuracy", 0.0))
+        record[M_VALID] = 1.0 if num_samples > 0 else 0.0
+        self._ext_pending[slot] = (flat, record)
+        if client_id is not None:
+            self._ext_names[slot] = str(client_id)
+
+    def _load_external(self) -> None:
+        """Pending submissions -> the external rows and their records (rank 0), then to
+        every rank.  Eager, host-driven: a round with external slots is not graph-captured."""
+        rec = torch.zeros(self._E, METRIC_COLUMNS, dtype=torch.float32)
+        if self.comm.is_root:
+            for slot, (flat, record) in self._ext_pending.items():
+                self._ext_rows[slot].copy_(flat)
+                rec[slot] = torch.tensor(record)
+            self._ext_pending.clear()
+        self._ext_records.copy_(rec)
+        if self.comm.collective:
+            self.comm.broadcast(self._ext_records, src=0)
+            self.comm.broadcast(self._ext_full.view(-1), src=0)
+
     # -- the round --------------------------------------------------------
     def run_round(self, flush: bool | None = None, prefetch_next: bool | None = None) -> RoundReport:
         """One federated round.  ``flush=False`` leaves the round's persistence
@@ -638,7 +698,7 @@ class FederatedEngine:
                 self._pack_event.synchronize()
         else:
             host = self._host_pack.cpu()
-        K, W = self._K, comm.world_size
+        K, W = self._KT, comm.world_size
         rec = host[: K * METRIC_COLUMNS].view(K, METRIC_COLUMNS).numpy()
         flags = host[K * METRIC_COLUMNS : K * METRIC_COLUMNS + 4]
         control = host[K * METRIC_COLUMNS + 4 :]
@@ -742,7 +802,7 @@ class FederatedEngine:
             and not eager and local is not None
             # (the blinding masks take the round number as their stream offset: a kernel
             # argument, frozen in a recorded graph)
-            and self.cfg.secure_agg == "none"
+            and self.cfg.secure_agg == "none" and self._E == 0
         )
         if graphable:
             if self._tail_graph is None and self._tail_rounds >= 1:
@@ -790,15 +850,28 @@ class FederatedEngine:
             else:
                 gathered = comm.allgather(rec)  # [W, max_local + 1, M]
                 if self._even:
-                    self._records.copy_(gathered[:, : self.max_local].reshape(K, M))
+                    self._records[:K].copy_(gathered[:, : self.max_local].reshape(K, M))
                 else:
-                    self._records.copy_(torch.cat(
+                    self._records[:K].copy_(torch.cat(
                         [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
                     ))
                 records = self._records
                 self._control.copy_(gathered[:, self.max_local, 0])
+            if self._E:
+                # the rows of outside clients: loaded, screened like the others, appended
+                self._load_external()
+                if cfg.validate_updates:
+                    ops.screen_rows(
+                        self._ext_rows, self._ext_records, M_UPDATE_SQNORM, M_VALID,
+                        ref=self.global_arena.data if self._need_delta else None,
+                        max_norm=cfg.max_update_norm,
+                    )
+                if records is not self._records:
+                    self._records[:K].copy_(records)
+                self._records[K:].copy_(self._ext_records)
+                records = self._records
         with timer.phase("reduce") if timer is not None else nullcontext():
-            self._reduce_select(records, G, K, M)
+            self._reduce_select(records, G, self._KT, M)
 
     def _reduce_select(self, records: torch.Tensor, G: int, K: int, M: int) -> None:
         cfg, comm = self.cfg, self.comm
@@ -843,8 +916,15 @@ class FederatedEngine:
         Otherwise: fused weighted sum of the local rows, then the library's all-reduce."""
         comm = self.comm
         algo = self._reduce_algo()
+        K = self._K
         if not comm.collective or algo != "ordered":
-            ops.weighted_sum(self.pool.rows(), weights[lo : lo + G], out=self._partial)
+            rows, w = self.pool.rows(), weights[lo : lo + G]
+            if self._E and comm.is_root:
+                # (one rank adds the outside rows; in one process the chain of additions is
+                # the one a K + E client engine runs)
+                rows = rows + [self._ext_rows[e] for e in range(self._E)]
+                w = torch.cat([w, weights[K:]])
+            ops.weighted_sum(rows, w, out=self._partial)
             if comm.collective:
                 comm.allreduce_sum(self._partial_full, algo=algo)
             return
@@ -872,6 +952,9 @@ class FederatedEngine:
             first += count
         # client order = rank-major order of the block placement, so `index` is 0..K-1
         assert index == list(range(self._K))
+        # ... followed by this rank's slice of the outside rows (every rank holds them whole)
+        for e in range(self._E):
+            sources.append(self._ext_full[e, comm.rank * per : (comm.rank + 1) * per])
         ops.weighted_sum(sources, weights, out=self._ordered_shard)
         comm.allgather_shards(self._partial_full, self._ordered_shard)
 
@@ -921,7 +1004,7 @@ class FederatedEngine:
             agg["privacy_epsilon"] = float(rec[:, M_EPSILON].max())
         clients = [
             {
-                "client_id": f"client_{cid}",
+                "client_id": f"client_{cid}" if cid < self._K else self._ext_names[cid - self._K],
                 "metrics": {
                     "loss": float(rec[cid, M_LOSS]),
                     "accuracy": float(rec[cid, M_ACC]),

@@ -19,14 +19,21 @@ A program written against the reference switches by swapping class names::
     async for metrics in coordinator.start_training():
         ...
 
-With a ``server`` (``InNodeServer`` or ``HTTPServer``) attached, outside readers
-fetch the current global model and the termination flag the way the reference's
-clients do; they do not take part in the rounds.
+With a ``server`` (``InNodeServer`` or ``HTTPServer``) attached, outside clients fetch
+the current global model and the termination flag the way the reference's clients do.
+When the engine has ``external_slots``, the updates they submit for the current round
+take part in it as extra rows of the same device reduction (weight ``num_samples``, same
+screening): a *mixed* round of resident and outside clients.  ``external_updates`` is the
+number of outside updates a round waits for (up to ``round_timeout``; 0 = take what has
+arrived).  While a server is attached the round itself runs on a worker thread of its own,
+so the event loop keeps answering ``/status`` and ``/model`` during a long round.
 """
 
 from __future__ import annotations
 
 import asyncio
+import time
+from concurrent.futures import ThreadPoolExecutor
 from datetime import datetime
 from pathlib import Path
 from typing import TYPE_CHECKING, Any, AsyncGenerator, Callable
@@ -75,10 +82,19 @@ class DeviceCoordinator:
         engine: "FederatedEngine",
         config: CoordinatorConfig,
         server: Any | None = None,
+        external_updates: int = 0,
+        background_rounds: bool | None = None,
     ) -> None:
         self._engine = engine
         self._config = config
         self._server = server
+        self._external_updates = int(external_updates)
+        if self._external_updates > engine.cfg.external_slots:
+            raise ValueError("external_updates exceeds the engine's external_slots")
+        self._slots: dict[str, int] = {}  # outside client id -> its arena row
+        # rounds off the event loop: on by default when somebody may be asking the server
+        self._background = server is not None if background_rounds is None else background_rounds
+        self._worker: ThreadPoolExecutor | None = None
         self._logger = Logger()
         self._clients: dict[str, ClientInfo] = {}
         self._round_metrics: list[RoundMetrics] = []
@@ -105,6 +121,8 @@ class DeviceCoordinator:
         server: Any | None = None,
         comm: Any | None = None,
         data: Any | None = None,
+        external_updates: int = 0,
+        background_rounds: bool | None = None,
         **engine_kwargs: Any,
     ) -> "DeviceCoordinator":
         """Build the engine from the reference-style configs and wrap it."""
@@ -114,7 +132,7 @@ class DeviceCoordinator:
             engine_config_from(config, training, **engine_kwargs),
             comm=comm, data=data, base_dir=config.base_dir,
         )
-        return cls(engine, config, server)
+        return cls(engine, config, server, external_updates, background_rounds)
 
     # -- accessors -----------------------------------------------------------
     @property
@@ -169,6 +187,46 @@ class DeviceCoordinator:
         else:
             self._server._current_round = self.current_round
 
+    # -- outside clients -------------------------------------------------------
+    async def _collect_external(self) -> None:
+        """Move what outside clients submitted for this round into the engine's external
+        rows; wait (at most ``round_timeout``) until ``external_updates`` of them are there."""
+        slots = self._engine.cfg.external_slots
+        server = self._server
+        if not slots or server is None or not hasattr(server, "_updates"):
+            return
+        deadline = time.monotonic() + float(self._config.round_timeout)
+        while len(server._updates) < self._external_updates and time.monotonic() < deadline:
+            await asyncio.sleep(0.005)
+        async with server._lock:
+            updates = dict(server._updates)
+            server._updates.clear()
+        for cid, update in updates.items():
+            slot = self._slots.get(cid)
+            if slot is None:
+                if len(self._slots) >= slots:
+                    self._logger.warning(f"no external slot left for client {cid}; update dropped")
+                    continue
+                slot = self._slots[cid] = len(self._slots)
+            m = dict(update.get("metrics") or {})
+            n = float(m.get("num_samples") or m.get("samples_processed") or 1.0)
+            self._engine.submit_external(slot, update["model_state"], n, m, client_id=cid)
+
+    def _run_round(self):
+        # inside start_training the engine queues the next round on the device while
+        # this one's report is being built and handed out
+        return self._engine.run_round(prefetch_next=self._more_rounds)
+
+    def _on_worker(self):
+        """The round on the coordinator's worker thread (one thread for every round, so
+        HIP's current device and torch's current stream are the same from round to round)."""
+        import torch
+
+        dev = self._engine.device
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        return self._run_round()
+
     # -- the round -----------------------------------------------------------
     async def train_round(self) -> RoundMetrics:
         """One round on the device plane.  Like the reference's round it raises
@@ -179,11 +237,14 @@ class DeviceCoordinator:
                 self._status = RoundStatus.IN_PROGRESS
                 self._sync_server_round()
                 try:
-                    # synchronous on purpose: HIP's current device and torch's
-                    # current stream belong to this thread
-                    # inside start_training the engine queues the next round on the
-                    # device while this one's report is being built and handed out
-                    report = self._engine.run_round(prefetch_next=self._more_rounds)
+                    await self._collect_external()
+                    if self._background:
+                        if self._worker is None:
+                            self._worker = ThreadPoolExecutor(1, thread_name_prefix="nanofed-round")
+                        report = await asyncio.get_running_loop().run_in_executor(
+                            self._worker, self._on_worker)
+                    else:
+                        report = self._run_round()
                 except Exception as exc:
                     self._status = RoundStatus.FAILED
                     self._logger.error(f"Error in round {self.current_round}: {exc}")
@@ -261,4 +322,7 @@ class DeviceCoordinator:
                 self._logger.info("Training completed")
 
     def close(self) -> None:
+        if self._worker is not None:
+            self._worker.shutdown(wait=True)
+            self._worker = None
         self._engine.close()

@@ -138,3 +138,66 @@ def test_device_coordinator_rounds_on_the_native_trainer(tmp_path):
                                rtol=0, atol=0)
     coordinator.close()
     plain.close()
+
+
+def test_mixed_round_on_the_native_trainer_with_rounds_on_the_worker_thread(tmp_path):
+    """Six resident clients on the hand-written kernels + two clients that submit through
+    the coordinator's in-node server, the round itself on the coordinator's worker thread
+    (a server is attached): bit-identical to the eight-client engine, and the event loop
+    gets its turns while the device trains."""
+    from dataclasses import replace
+
+    from nanofed_amd.communication.innode import InNodeClient, InNodeServer
+    from nanofed_amd.engine import EngineConfig
+    from nanofed_amd.engine.data import build_federated_data
+
+    torch.cuda.set_device(0)
+    base = dict(model="mnist_cnn", samples_per_client=512, batch_size=64, local_epochs=1,
+                eval_samples=256, learning_rate=0.1, placement_invariant=True, seed=3)
+    full_cfg = EngineConfig(num_clients=8, **base)
+    data = build_federated_data(full_cfg)
+    ref = FederatedEngine(full_cfg, comm=Communicator(device=torch.device("cuda", 0)), data=data)
+    ref.run_round()
+    torch.cuda.synchronize()
+
+    async def main():
+        server = InNodeServer("mixed-gpu")
+        await server.start()
+        coord = DeviceCoordinator.create(
+            CoordinatorConfig(num_rounds=1, min_clients=6, min_completion_rate=1.0,
+                              round_timeout=60, base_dir=tmp_path / "run"),
+            server=server, comm=Communicator(device=torch.device("cuda", 0)),
+            data=replace(data, shards=data.shards[:6]), external_updates=2, external_slots=2,
+            **base)
+        assert coord.engine.backend == "native" and coord._background
+        ticks = []
+        done = asyncio.Event()
+
+        async def outsider(k):
+            async with InNodeClient(server, f"outside_{k}") as client:
+                _, rnd = await client.fetch_global_model()
+                assert rnd == 0
+                assert await client.submit_update(ref.pool[k].state_dict("cpu"),
+                                                  {"loss": 1.0, "accuracy": 0.5, "num_samples": 512})
+
+        async def poller():
+            while not done.is_set():
+                ticks.append(server.status()["num_updates"])
+                await asyncio.sleep(0.001)
+
+        async def rounds():
+            try:
+                return [m async for m in coord.start_training()]
+            finally:
+                done.set()
+
+        _, _, _, metrics = await asyncio.gather(outsider(6), outsider(7), poller(), rounds())
+        await server.stop()
+        return coord, metrics, ticks
+
+    coord, metrics, ticks = asyncio.run(main())
+    assert metrics[0].num_clients == 8 and metrics[0].status.name == "COMPLETED"
+    assert torch.equal(coord.engine.global_arena.data, ref.global_arena.data)
+    assert len(ticks) >= 2
+    coord.close()
+    ref.close()
