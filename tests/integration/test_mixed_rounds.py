@@ -155,3 +155,61 @@ def test_the_event_loop_keeps_running_while_a_round_trains(tmp_path):
     seen, metrics = asyncio.run(main())
     assert metrics.status.name == "COMPLETED"
     assert len(seen) >= 5, "the poller never ran during the round"
+
+
+MIXED_WORKER = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from nanofed_amd.engine import EngineConfig, FederatedEngine
+from nanofed_amd.parallel import Communicator
+comm = Communicator.from_env(backend="gloo", device="cpu")
+eng = FederatedEngine(EngineConfig(**{cfg!r}), comm=comm)
+reports = []
+for r in range(2):
+    if comm.is_root:
+        for slot in range(2 - r):  # two outside updates in round 0, one in round 1
+            gen = torch.Generator().manual_seed(100 * r + slot)
+            delta = 0.01 * torch.randn(eng.layout.numel, generator=gen)
+            eng.submit_external(slot, eng.global_arena.data + delta, 40 + 8 * slot)
+    reports.append(eng.run_round())
+if comm.is_root:
+    torch.save({{"flat": eng.global_arena.data, "n": [r.num_clients for r in reports],
+                "weights": [c["weight"] for c in reports[-1].client_metrics]}}, {out!r})
+eng.close()
+comm.finish(0)
+"""
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_mixed_rounds_on_several_ranks_equal_the_one_process_run(tmp_path, nproc):
+    """Rank 0 takes the outside updates and broadcasts them; every rank adds its slice of
+    them after the resident clients' slices, in one order: the model has the bits of the
+    one-process run (six resident clients on 2 and on 3 ranks)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_multiprocess_engine import _env, _free_port
+
+    conf = dict(vars(cfg(external_slots=2)))
+
+    def run(n, name):
+        out = tmp_path / f"{name}.pt"
+        script = tmp_path / f"{name}.py"
+        script.write_text(MIXED_WORKER.format(root=root, cfg=conf, out=str(out)))
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, str(script)], cwd=root, stderr=subprocess.PIPE,
+                                  text=True, env=_env(RANK=str(k), WORLD_SIZE=str(n),
+                                                      LOCAL_RANK=str(k), MASTER_PORT=str(port)))
+                 for k in range(n)]
+        for p in procs:
+            _, err = p.communicate(timeout=300)
+            assert p.returncode == 0, err[-2000:]
+        return torch.load(out, weights_only=False)
+
+    one, many = run(1, "one"), run(nproc, "many")
+    assert one["n"] == many["n"] == [8, 7]
+    assert many["weights"] == one["weights"]
+    assert torch.equal(many["flat"], one["flat"])
