@@ -130,7 +130,7 @@ def supports(cfg: EngineConfig) -> bool:
     work on 64 rows at a time: a smaller batch is one partly filled pass, a
     larger one several passes whose gradients are added up before the SGD
     update.  DP-SGD is built for the batch of 64."""
-    if cfg.model != "mnist_cnn" or cfg.model_kwargs:
+    if cfg.model != "mnist_cnn" or set(cfg.model_kwargs) - {"dropout"}:
         return False
     if cfg.dp is not None:
         return cfg.dp.mode == "per_sample" and cfg.batch_size == BATCH
@@ -318,7 +318,10 @@ class NativeBuffers:
         c.lr = cfg.learning_rate if cfg else 0.0
         c.wd = cfg.weight_decay if cfg else 0.0
         c.mean, c.inv_std = mean, 1.0 / std
-        c.p_drop1, c.p_drop2 = 0.25, 0.5
+        # model_kwargs={"dropout": False} builds the network without dropout (numerics
+        # checks against fp32 with nothing random in the step)
+        dropout = bool(cfg.model_kwargs.get("dropout", True)) if cfg is not None else True
+        c.p_drop1, c.p_drop2 = (0.25, 0.5) if dropout else (0.0, 0.0)
         self.ctx = c
 
     def stream(self) -> c_void_p:

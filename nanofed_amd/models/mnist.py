@@ -20,12 +20,14 @@ import torch.nn.functional as F
 
 
 class MNISTModel(nn.Module):
-    def __init__(self) -> None:
+    def __init__(self, dropout: bool = True) -> None:
+        """``dropout=False`` keeps the two dropout layers as identities (p = 0): a
+        deterministic network for numerics comparisons; the default is the reference's."""
         super().__init__()
         self.conv1 = nn.Conv2d(1, 32, 3, 1)
         self.conv2 = nn.Conv2d(32, 64, 3, 1)
-        self.dropout1 = nn.Dropout(0.25)
-        self.dropout2 = nn.Dropout(0.5)
+        self.dropout1 = nn.Dropout(0.25 if dropout else 0.0)
+        self.dropout2 = nn.Dropout(0.5 if dropout else 0.0)
         self.fc1 = nn.Linear(9216, 128)
         self.fc2 = nn.Linear(128, 10)
 
