@@ -79,6 +79,8 @@ def run_engine(name: str, args) -> dict:
         "trainer": type(engine.trainer).__name__,
         "train_loss": reports[-1].agg_metrics["loss"],
         "train_accuracy": reports[-1].agg_metrics["accuracy"],
+        "phases_ms": {k: round(sum(r.phases_ms.get(k, 0.0) for r in reports) / len(reports), 3)
+                      for k in sorted({k for r in reports for k in r.phases_ms})},
         "eval": ev, "data": "synthetic", "dtype": cfg.dtype,
         "status": [r.status for r in reports],
     }

@@ -170,6 +170,9 @@ class GPT2NativeTrainer(GroupTrainer):
             self.group = min(GROUP, G)
             self._ggrads = torch.zeros(self.group, n, dtype=BF16, device=self.device)
             self._gslabs = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._host_tokens: torch.Tensor | None = None
+        self._step_graphs: dict[tuple[int, int], torch.cuda.CUDAGraph] = {}
+        self._step_inputs: dict[tuple[int, int], dict] = {}
 
     # -- buffers ------------------------------------------------------------
     def _buffers(self, batch: int, seq: int, lane: int = 0) -> _Buffers:
@@ -341,9 +344,12 @@ class GPT2NativeTrainer(GroupTrainer):
         self._gemm(gemm_ops.TN, dy, x, dw, n_out or N, K, R, dy.stride(0),
                    x.stride(0), K, Gn, R * dy.stride(0), R * x.stride(0), dw.stride)
 
-    def _gstep(self, g0: int, Gn: int, tokens: torch.Tensor) -> None:
+    def _gstep(self, g0: int, Gn: int, tokens: torch.Tensor,
+               order: torch.Tensor | None = None) -> None:
         """One optimisation step of Gn clients; ``tokens`` ``[Gn * batch, seq + 1]``,
-        client-major."""
+        client-major.  ``order`` ``[Gn, 2, batch * seq]``: per client the sorted input tokens
+        and their stable sort order (drawn on the host with the batch); without it the
+        embedding gradient sorts on the device."""
         cfg, m, L = self.cfg, self.m, self.m.n_layer
         nb = tokens.shape[0] // Gn                       # sequences per client
         b = self._buffers(tokens.shape[0], tokens.shape[1] - 1, lane=100 + Gn)
@@ -421,7 +427,9 @@ class GPT2NativeTrainer(GroupTrainer):
                  dxsum=f"h.{l - 1}.c_proj.bias" if l > 0 else None)
         for j in range(Gn):
             nn_ops.embed_bwd(inp[j * nb : (j + 1) * nb], b.dres[rows[j]], gs[j]["wte.weight"],
-                             gs[j]["wpe.weight"], nb, b.seq)
+                             gs[j]["wpe.weight"], nb, b.seq,
+                             sorted_tokens=order[j, 0] if order is not None else None,
+                             order=order[j, 1] if order is not None else None)
         n = self.layout.numel
         nn_ops.sgd_step_bf16g(self.pool.data[g0 : g0 + Gn].view(-1), self._ggrads[:Gn].view(-1),
                               self.shadow[g0 : g0 + Gn].view(-1), cfg.learning_rate,
@@ -435,6 +443,8 @@ class GPT2NativeTrainer(GroupTrainer):
         cfg = self.cfg
         G, B = len(self.pool), cfg.batch_size
         steps = self.shards.steps_per_epoch(0)
+        if cfg.graph_capture:
+            return self._train_round_graphs(round_idx, steps)
         for epoch in range(cfg.local_epochs):
             self._acc.zero_()
             perms = torch.stack([self.shards.epoch_permutation(k, round_idx, epoch)
@@ -444,6 +454,66 @@ class GPT2NativeTrainer(GroupTrainer):
                     Gn = min(self.group, G - g0)
                     rows = perms[g0 : g0 + Gn, s].reshape(-1)
                     self._gstep(g0, Gn, self.shards.inputs[rows])
+
+    def _train_round_graphs(self, round_idx: int, steps: int) -> None:
+        """The grouped step as one hipGraph replay per step and group.  What changes from
+        step to step is the batch: its tokens and the sort order of its input tokens (for
+        the embedding gradient) are assembled on the host for the whole round - the host
+        holds a copy of the token shard and draws the shuffles itself - and copied into the
+        graph's static input buffers before each replay; the captured step holds no sort,
+        no gather and no allocation.  The first step of a (first client, group size) pair
+        runs eagerly on the same buffers (it warms the workspaces up), the second is
+        captured, every later one is a replay."""
+        cfg = self.cfg
+        G, B = len(self.pool), cfg.batch_size
+        S1 = self.shards.inputs.shape[1]
+        if self._host_tokens is None:
+            self._host_tokens = self.shards.inputs.cpu()
+        groups = [(g0, min(self.group, G - g0)) for g0 in range(0, G, self.group)]
+        E = cfg.local_epochs
+        # the round's batches, in page-locked memory: [epoch, step, client] blocks
+        tok = torch.empty(E, steps, G * B, S1, dtype=torch.int64).pin_memory()
+        order = torch.empty(E, steps, G, 2, B * (S1 - 1), dtype=torch.int64).pin_memory()
+        for epoch in range(E):
+            perms = torch.stack([self.shards.host_permutation(k, round_idx, epoch)
+                                 for k in range(G)]).view(G, steps, B)
+            for s in range(steps):
+                batch = self._host_tokens[perms[:, s].reshape(-1)]  # [G * B, S + 1]
+                tok[epoch, s].copy_(batch)
+                for k in range(G):
+                    srt, idx = nn_ops.token_order(batch[k * B : (k + 1) * B, :-1])
+                    order[epoch, s, k, 0].copy_(srt)
+                    order[epoch, s, k, 1].copy_(idx)
+        for epoch in range(E):
+            self._acc.zero_()
+            for s in range(steps):
+                for g0, Gn in groups:
+                    st = self._static_inputs(g0, Gn, S1)
+                    st["tokens"].copy_(tok[epoch, s, g0 * B : (g0 + Gn) * B], non_blocking=True)
+                    st["order"].copy_(order[epoch, s, g0 : g0 + Gn], non_blocking=True)
+                    graph = self._step_graphs.get((g0, Gn))
+                    if graph is None and st["warm"]:
+                        torch.cuda.synchronize(self.device)
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            self._gstep(g0, Gn, st["tokens"], st["order"])
+                        self._step_graphs[(g0, Gn)] = graph
+                    if graph is not None:
+                        graph.replay()
+                    else:
+                        self._gstep(g0, Gn, st["tokens"], st["order"])
+                        st["warm"] = True
+
+    def _static_inputs(self, g0: int, Gn: int, S1: int) -> dict:
+        key = (g0, Gn)
+        if key not in self._step_inputs:
+            B = self.cfg.batch_size
+            self._step_inputs[key] = {
+                "tokens": torch.zeros(Gn * B, S1, dtype=torch.int64, device=self.device),
+                "order": torch.zeros(Gn, 2, B * (S1 - 1), dtype=torch.int64, device=self.device),
+                "warm": False,
+            }
+        return self._step_inputs[key]
 
     def train_round(self, round_idx: int) -> torch.Tensor:
         cfg = self.cfg

@@ -104,16 +104,26 @@ def embed_fwd(tokens: torch.Tensor, wte: torch.Tensor, wpe: torch.Tensor, seq_le
 
 
 def embed_bwd(tokens: torch.Tensor, dx: torch.Tensor, dwte: torch.Tensor, dwpe: torch.Tensor,
-              batch: int, seq_len: int) -> None:
+              batch: int, seq_len: int, sorted_tokens: torch.Tensor | None = None,
+              order: torch.Tensor | None = None) -> None:
     """``dwte += scatter(dx by token)`` (in token-sorted order, no atomics) and
-    ``dwpe = sum over the batch``."""
+    ``dwpe = sum over the batch``.  ``sorted_tokens`` / ``order``: the stable sort of the
+    flat tokens when the caller has it already (``token_order``: drawn on the host with
+    the batch, so that a captured step holds no sort)."""
     _need(dx, torch.bfloat16, "dx")
     _need(dwte, torch.bfloat16, "dwte")
     _need(dwpe, torch.bfloat16, "dwpe")
     C = dx.shape[-1]
     flat = tokens.reshape(-1)
     if _gpu(dx):
-        srt, order = torch.sort(flat, stable=True)
+        if sorted_tokens is None or order is None:
+            srt, order = torch.sort(flat, stable=True)
+        else:
+            srt = sorted_tokens
+            for t, name in ((srt, "sorted_tokens"), (order, "order")):
+                _need(t, torch.int64, name)
+                if t.numel() != flat.numel():
+                    raise DeviceError(f"embed_bwd: {name} must have one entry per token")
         library.check(_fn("nf_embed_bwd")(_p(srt), _p(order), _p(dx), _p(dwte), _p(dwpe), batch,
                                           seq_len, C, library.stream_ptr(dx.device)), "embed_bwd")
     else:
@@ -121,6 +131,16 @@ def embed_bwd(tokens: torch.Tensor, dx: torch.Tensor, dwte: torch.Tensor, dwpe: 
         acc.index_add_(0, flat, dx.reshape(-1, C).float())
         dwte.copy_(acc.to(torch.bfloat16))
         dwpe[:seq_len].copy_(dx.reshape(batch, seq_len, C).float().sum(0).to(torch.bfloat16))
+
+
+def token_order(tokens_host: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """``(sorted tokens, order)`` of a host token tensor, flattened: what
+    ``torch.sort(flat, stable=True)`` returns, computed with numpy on the host."""
+    import numpy as np
+
+    flat = tokens_host.reshape(-1).numpy()
+    order = np.argsort(flat, kind="stable")
+    return torch.from_numpy(flat[order]), torch.from_numpy(order.astype(np.int64))
 
 
 def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor,

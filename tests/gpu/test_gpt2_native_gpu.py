@@ -161,3 +161,37 @@ def test_grouped_steps_train_the_same_model_as_client_after_client(monkeypatch):
     da, db = a - init, b - init
     cos = float(torch.dot(da, db) / (da.norm() * db.norm()))
     assert cos > 0.995, cos
+
+
+def test_captured_grouped_steps_equal_the_eager_ones_bit_for_bit(monkeypatch):
+    """The grouped step replayed from a hipGraph (batch tokens and their sort order come
+    from the host, copied into static buffers before each replay) against the eager step
+    (device gather, device sort): three rounds of four steps - one eager warm-up, one
+    capture, ten replays with the round's own eager work and synchronisations between them -
+    and chunks of 2 + 1 clients, i.e. two graphs.  Every round's loss and the final model
+    must have the same bits."""
+    from nanofed_amd.engine import gpt2_native
+
+    for group in (8, 2):
+        monkeypatch.setattr(gpt2_native, "GROUP", group)
+        outs = []
+        for capture in (False, True):
+            eng = _engine(num_clients=3, samples_per_client=16, learning_rate=0.1,
+                          graph_capture=capture)
+            assert eng.trainer.group == min(group, 3)
+            reps = [eng.run_round() for _ in range(3)]
+            torch.cuda.synchronize()
+            assert len(eng.trainer._step_graphs) == ((1 if group == 8 else 2) if capture else 0)
+            outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reps],
+                         [r.agg_metrics["accuracy"] for r in reps]))
+        assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+        assert torch.equal(outs[0][0], outs[1][0])
+
+
+def test_host_token_order_is_the_stable_device_sort():
+    from nanofed_amd.ops import nn_ops
+
+    toks = torch.randint(0, 50, (4, 128), dtype=torch.int64)
+    srt, order = nn_ops.token_order(toks)
+    want_s, want_o = torch.sort(toks.reshape(-1).cuda(), stable=True)
+    assert torch.equal(srt, want_s.cpu()) and torch.equal(order, want_o.cpu())
