@@ -98,6 +98,14 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1)
         # a very long reduction (the LM head's input gradient, K = 50257, cut along K):
         # 389 us against 472 us
         return GEO_256
+    if layout == TN and t256 >= 192 and ksteps >= 32 and min(M, N) >= 512:
+        # weight gradients of a group of clients: the big tile when its workgroups fill
+        # whole rounds of the 256 CUs (8 x 2304 x 768: 216 tiles, one round, 122 us against
+        # 152 us), not when a second round would be mostly empty (8 x 3072 x 768: 288
+        # tiles, 246 us against 222 us)
+        rounds = t256 / 256.0
+        if rounds / -(-t256 // 256) >= 0.8:
+            return GEO_256
     if layout == TN and t256 >= 224 and ksteps >= 32 and max(M, N) >= 16384 and min(M, N) >= 512:
         return GEO_256        # the LM head's weight gradient: one very long side (377 vs 408 us)
     if t256 >= 1024 and layout == NT:
