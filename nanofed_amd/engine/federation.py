@@ -311,7 +311,11 @@ class FederatedEngine:
         self._partial_full = torch.zeros(self.comm.padded_numel(self.layout.numel), **f32)
         self._partial = self._partial_full[: self.layout.numel]
         self._ordered_send: torch.Tensor | None = None
+        self._ordered_recv: torch.Tensor | None = None
         self._ordered_shard: torch.Tensor | None = None
+        self._gathered: torch.Tensor | None = None
+        self._segment_graphs: dict[str, torch.cuda.CUDAGraph] = {}
+        self._tail_local: torch.Tensor | None = None
         if cfg.reduce_algo not in ("auto", "ordered", "allreduce", "rs_ag"):
             raise DeviceError(f"unknown reduce_algo {cfg.reduce_algo!r}")
         # per-client records of this rank + one control row [failed flag, ...]
@@ -797,14 +801,14 @@ class FederatedEngine:
 
     # steps 3-7
     def _tail(self, local: torch.Tensor | None, failed: bool, eager: bool) -> None:
-        graphable = (
-            self.cfg.tail_graph and self.device.type == "cuda" and not self.comm.collective
-            and not eager and local is not None
+        cfg = self.cfg
+        quiet = (
+            cfg.tail_graph and self.device.type == "cuda" and not eager and local is not None
             # (the blinding masks take the round number as their stream offset: a kernel
             # argument, frozen in a recorded graph)
-            and self.cfg.secure_agg == "none" and self._E == 0
+            and cfg.secure_agg == "none" and self._E == 0
         )
-        if graphable:
+        if quiet and not self.comm.collective:
             if self._tail_graph is None and self._tail_rounds >= 1:
                 # captured on the second eager-free round: every buffer exists and the
                 # trainer's metrics tensor has its final address
@@ -819,18 +823,44 @@ class FederatedEngine:
                     self._tail_graph.replay()
                 self._tail_rounds += 1
                 return
-        self._tail_ops(local, failed, self._timer)
+        # Several ranks: the collectives stay eager (no library call is recorded), the
+        # device work between them is replayed from one graph per segment - recorded on
+        # the second quiet round, when every buffer has its final address.
+        segments = quiet and self.comm.collective and self._tail_rounds >= 1
+        if segments and self._tail_local is None:
+            self._tail_local = local
+        if segments and local.data_ptr() != self._tail_local.data_ptr():
+            segments = False
+        self._tail_ops(local, failed, self._timer, segments)
         self._tail_rounds += 1
 
-    def _tail_ops(self, local: torch.Tensor | None, failed: bool, timer: PhaseTimer | None = None) -> None:
+    def _segment(self, key: str, fn: Callable[[], None], replayable: bool) -> None:
+        """Run ``fn`` - eagerly, or (``replayable``) as a hipGraph recorded at its first
+        replayable call.  ``fn`` must touch only buffers whose addresses never change."""
+        if not replayable:
+            fn()
+            return
+        graph = self._segment_graphs.get(key)
+        if graph is None:
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fn()
+            self._segment_graphs[key] = graph
+        graph.replay()
+
+    def _tail_ops(self, local: torch.Tensor | None, failed: bool, timer: PhaseTimer | None = None,
+                  segments: bool = False) -> None:
         """Steps 3-7.  ``timer`` is None while the steps are being recorded into a
-        graph (events cannot be taken inside a capture)."""
+        graph (events cannot be taken inside a capture).  ``segments``: replay the device
+        work between the collectives from graphs (see ``_tail``)."""
         from contextlib import nullcontext
 
         cfg, comm = self.cfg, self.comm
         G, K, M = len(self.client_ids), self._K, METRIC_COLUMNS
         rec = self._local_records
-        with timer.phase("screen_gather") if timer is not None else nullcontext():
+
+        def screen() -> None:
             rec.zero_()
             if local is not None and not failed:
                 rec[:G].copy_(local)
@@ -843,44 +873,99 @@ class FederatedEngine:
                     )
             if failed:
                 rec[self.max_local, 0] = 1.0
-            # 4. gather the per-client records (+ control rows)
-            if not comm.collective:
-                records = rec[:K]
-                self._control.copy_(rec[self.max_local, :1])
-            else:
-                gathered = comm.allgather(rec)  # [W, max_local + 1, M]
-                if self._even:
-                    self._records[:K].copy_(gathered[:, : self.max_local].reshape(K, M))
-                else:
-                    self._records[:K].copy_(torch.cat(
-                        [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
-                    ))
-                records = self._records
-                self._control.copy_(gathered[:, self.max_local, 0])
-            if self._E:
-                # the rows of outside clients: loaded, screened like the others, appended
-                self._load_external()
-                if cfg.validate_updates:
-                    ops.screen_rows(
-                        self._ext_rows, self._ext_records, M_UPDATE_SQNORM, M_VALID,
-                        ref=self.global_arena.data if self._need_delta else None,
-                        max_norm=cfg.max_update_norm,
-                    )
-                if records is not self._records:
-                    self._records[:K].copy_(records)
-                self._records[K:].copy_(self._ext_records)
-                records = self._records
-        with timer.phase("reduce") if timer is not None else nullcontext():
-            self._reduce_select(records, G, self._KT, M)
 
-    def _reduce_select(self, records: torch.Tensor, G: int, K: int, M: int) -> None:
-        cfg, comm = self.cfg, self.comm
-        # 5. anomaly screen, weights, quorum flag: one launch
+        def assemble() -> torch.Tensor:
+            # 4b. the K records in client order (+ the ranks' control flags)
+            if not comm.collective:
+                self._control.copy_(rec[self.max_local, :1])
+                return rec[:K]
+            gathered = self._gathered  # [W, max_local + 1, M]
+            if self._even:
+                self._records[:K].copy_(gathered[:, : self.max_local].reshape(K, M))
+            else:
+                self._records[:K].copy_(torch.cat(
+                    [gathered[w, :c] for w, c in enumerate(self._rank_counts)], dim=0
+                ))
+            self._control.copy_(gathered[:, self.max_local, 0])
+            return self._records
+
+        with timer.phase("screen_gather") if timer is not None else nullcontext():
+            self._segment("screen", screen, segments)
+            # 4a. gather the per-client records (+ control rows)
+            if comm.collective:
+                if self._gathered is None:
+                    self._gathered = torch.zeros(comm.world_size, *rec.shape, dtype=rec.dtype,
+                                                 device=rec.device)
+                comm.allgather(rec, out=self._gathered)
+        with timer.phase("reduce") if timer is not None else nullcontext():
+            if cfg.secure_agg == "pairwise" or self._E:
+                records = assemble()
+                if self._E:
+                    records = self._append_external(records)
+                self._reduce_select(records, G, self._KT, M)
+                return
+            # 5-7 in segments around the collectives of the reduce
+            algo = self._reduce_algo()
+            ordered = comm.collective and algo == "ordered"
+            lo = self.client_ids[0]
+
+            def pre() -> None:
+                records = assemble()
+                self._weigh(records)
+                if ordered:
+                    self._ordered_fill_send(G)
+                else:
+                    ops.weighted_sum(self.pool.rows(), self._weights[lo : lo + G], out=self._partial)
+                # (the records are final here: into the host's buffer with them)
+                self._host_pack[: K * M].copy_(records.reshape(-1))
+
+            def mid() -> None:
+                ops.weighted_sum(self._ordered_sources(self._ordered_recv), self._weights,
+                                 out=self._ordered_shard)
+
+            def post() -> None:
+                # 7. quorum select (device-side; the old model survives a failed round)
+                ops.select_copy(self.global_arena.data, self._partial, self._flags)
+                self._host_pack[K * M : K * M + 4].copy_(self._flags)
+                self._host_pack[K * M + 4 :].copy_(self._control)
+
+            self._segment("pre", pre, segments)
+            if ordered:
+                comm.exchange_row_shards(self._ordered_send, out=self._ordered_recv)
+                self._segment("mid", mid, segments)
+                comm.allgather_shards(self._partial_full, self._ordered_shard)
+            elif comm.collective:
+                comm.allreduce_sum(self._partial_full, algo=algo)
+            self._segment("post", post, segments)
+
+    def _append_external(self, records: torch.Tensor) -> torch.Tensor:
+        """The rows of outside clients: loaded, screened like the others, appended."""
+        cfg, K = self.cfg, self._K
+        self._load_external()
+        if cfg.validate_updates:
+            ops.screen_rows(
+                self._ext_rows, self._ext_records, M_UPDATE_SQNORM, M_VALID,
+                ref=self.global_arena.data if self._need_delta else None,
+                max_norm=cfg.max_update_norm,
+            )
+        if records is not self._records:
+            self._records[:K].copy_(records)
+        self._records[K:].copy_(self._ext_records)
+        return self._records
+
+    def _weigh(self, records: torch.Tensor) -> None:
+        """5. anomaly screen, weights, quorum flag: one launch."""
+        cfg = self.cfg
         ops.round_weights(
             records, M_SAMPLES, M_VALID, M_UPDATE_SQNORM, float(cfg.required_clients()),
             self._weights, self._flags, z_threshold=cfg.zscore_threshold,
             min_clients_for_stats=cfg.min_clients_for_stats,
         )
+
+    def _reduce_select(self, records: torch.Tensor, G: int, K: int, M: int) -> None:
+        """Steps 5-7 in one piece (rounds under pairwise masking or with outside rows)."""
+        cfg = self.cfg
+        self._weigh(records)
         lo = self.client_ids[0]
         # 6. FedAvg: fused local weighted sum + one all-reduce (rows with weight 0
         #    are never read, so a poisoned row cannot leak NaNs)
@@ -928,35 +1013,40 @@ class FederatedEngine:
             if comm.collective:
                 comm.allreduce_sum(self._partial_full, algo=algo)
             return
+        self._ordered_fill_send(G)
+        comm.exchange_row_shards(self._ordered_send, out=self._ordered_recv)
+        ops.weighted_sum(self._ordered_sources(self._ordered_recv), weights, out=self._ordered_shard)
+        comm.allgather_shards(self._partial_full, self._ordered_shard)
+
+    def _ordered_fill_send(self, G: int) -> None:
+        """Block s of the send buffer = slice s of this rank's rows (rows beyond G and the
+        tail of the last slice stay zero: they carry weight 0 / are cut off)."""
+        comm = self.comm
         W, R, n = comm.world_size, self.max_local, self.layout.numel
         per = comm.shard_numel(n)
         if self._ordered_send is None:
-            self._ordered_send = torch.zeros(W, R, per, dtype=torch.float32, device=self.device)
-            self._ordered_shard = torch.zeros(per, dtype=torch.float32, device=self.device)
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._ordered_send = torch.zeros(W, R, per, **f32)
+            self._ordered_recv = torch.zeros(W, R, per, **f32)
+            self._ordered_shard = torch.zeros(per, **f32)
         send = self._ordered_send
-        # block s of `send` = slice s of my rows (rows beyond G and the tail of the last
-        # slice stay zero and carry weight 0 / are cut off)
         rows = self.pool.data  # [G, n]
         whole = n // per  # slices that lie completely inside a row
         if whole:
             send[:whole, :G].copy_(rows[:, : whole * per].view(G, whole, per).transpose(0, 1))
         if whole < W and n > whole * per:
             send[whole, :G, : n - whole * per].copy_(rows[:, whole * per :])
-        recv = comm.exchange_row_shards(send)  # [W, R, per]: slice `rank` of rank w's rows
-        sources, index = [], []
-        first = 0
-        for w, count in enumerate(self._rank_counts):
-            for i in range(count):
-                sources.append(recv[w, i])
-                index.append(first + i)
-            first += count
-        # client order = rank-major order of the block placement, so `index` is 0..K-1
-        assert index == list(range(self._K))
-        # ... followed by this rank's slice of the outside rows (every rank holds them whole)
+
+    def _ordered_sources(self, recv: torch.Tensor) -> list[torch.Tensor]:
+        """Slice ``rank`` of every client row, in client order (= rank-major order of the
+        block placement), followed by this rank's slice of the outside rows."""
+        comm = self.comm
+        per = comm.shard_numel(self.layout.numel)
+        sources = [recv[w, i] for w, count in enumerate(self._rank_counts) for i in range(count)]
+        assert len(sources) == self._K
         for e in range(self._E):
             sources.append(self._ext_full[e, comm.rank * per : (comm.rank + 1) * per])
-        ops.weighted_sum(sources, weights, out=self._ordered_shard)
-        comm.allgather_shards(self._partial_full, self._ordered_shard)
+        return sources
 
     def _secure_reduce(self, records: torch.Tensor, lo: int, G: int) -> None:
         """FedAvg under pairwise masking (reference capability: the share sums of
@@ -1214,6 +1304,7 @@ class FederatedEngine:
         self._prelaunched = None
         self._timer.collect()
         self._tail_graph = None  # recaptured on a quiet round
+        self._segment_graphs = {}
         self._tail_rounds = 0
         if self._persister is not None:
             try:

@@ -293,19 +293,31 @@ class Communicator:
             t.copy_(buf[:n])
 
     # -- transport of the ordered reduce ------------------------------------
-    def exchange_row_shards(self, send: torch.Tensor) -> torch.Tensor:
+    def exchange_row_shards(self, send: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """All-to-all of row slices.  ``send``: ``[world, R, per]`` - block ``s`` holds
         slice ``s`` of this rank's R rows.  Returns ``[world, R, per]`` whose block ``w``
-        holds slice ``rank`` of rank w's rows."""
+        holds slice ``rank`` of rank w's rows (written into ``out`` when given: a buffer
+        with a fixed address, for callers that replay recorded work on the result)."""
         if send.dim() != 3 or send.shape[0] != self.world_size or not send.is_contiguous():
             raise DeviceError("exchange_row_shards expects a contiguous [world, rows, per] tensor")
+        if out is not None and (out.shape != send.shape or out.dtype != send.dtype
+                                or out.device != send.device or not out.is_contiguous()):
+            raise DeviceError("exchange_row_shards: out must match the send buffer")
         if self._single:
-            return send
+            if out is None:
+                return send
+            out.copy_(send)
+            return out
         staged = self._host_staged(send)
         src = send.detach().to("cpu") if staged else send
-        out = torch.empty_like(src)
-        dist.all_to_all_single(out, src, group=self.group)
-        return out.to(send.device) if staged else out
+        dst = out if (out is not None and not staged) else torch.empty_like(src)
+        dist.all_to_all_single(dst, src, group=self.group)
+        if not staged:
+            return dst
+        if out is None:
+            return dst.to(send.device)
+        out.copy_(dst)
+        return out
 
     def allgather_shards(self, full: torch.Tensor, shard: torch.Tensor) -> torch.Tensor:
         """``full[w * per : (w + 1) * per] = rank w's shard`` on every rank, in place."""
@@ -322,17 +334,30 @@ class Communicator:
             dist.all_gather_into_tensor(full, shard.contiguous(), group=self.group)
         return full
 
-    def allgather(self, local: torch.Tensor) -> torch.Tensor:
-        """``[world, *local.shape]`` stack of every rank's tensor."""
+    def allgather(self, local: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """``[world, *local.shape]`` stack of every rank's tensor (in ``out`` when given)."""
+        want = (self.world_size, *local.shape)
+        if out is not None and (tuple(out.shape) != want or out.dtype != local.dtype
+                                or out.device != local.device or not out.is_contiguous()):
+            raise DeviceError("allgather: out must be a contiguous [world, *local.shape] tensor")
         if self._single:
-            return local.unsqueeze(0).clone()
+            if out is None:
+                return local.unsqueeze(0).clone()
+            out.copy_(local.unsqueeze(0))
+            return out
         staged = self._host_staged(local)
         src = local.detach().to("cpu") if staged else local.contiguous()
         flat = src.reshape(-1)
-        out = torch.empty(self.world_size * flat.numel(), dtype=src.dtype, device=src.device)
-        dist.all_gather_into_tensor(out, flat, group=self.group)
-        out = out.view(self.world_size, *src.shape)
-        return out.to(local.device) if staged else out
+        if out is not None and not staged:
+            dist.all_gather_into_tensor(out.view(-1), flat, group=self.group)
+            return out
+        res = torch.empty(self.world_size * flat.numel(), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(res, flat, group=self.group)
+        res = res.view(want)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res.to(local.device) if staged else res
 
     def max_over_ranks(self, value: float) -> float:
         if self._single:

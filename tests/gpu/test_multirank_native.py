@@ -30,7 +30,8 @@ reps = eng.run({rounds!r})
 torch.cuda.synchronize()
 if comm.is_root:
     torch.save({{"flat": eng.global_arena.data.cpu(), "loss": reps[-1].agg_metrics["loss"],
-                "weights": [c["weight"] for c in reps[-1].client_metrics]}}, {out!r})
+                "weights": [c["weight"] for c in reps[-1].client_metrics],
+                "segments": sorted(eng._segment_graphs)}}, {out!r})
 comm.finish(0)
 """
 
@@ -66,6 +67,7 @@ def test_ranks_sharing_the_gpu_give_the_bits_of_one_rank(tmp_path, nproc):
     single = FederatedEngine(EngineConfig(**CFG), comm=Communicator(device=torch.device("cuda", 0)))
     reps = single.run(3)
     assert dist["weights"] == pytest.approx([320 / 896, 256 / 896, 192 / 896, 128 / 896])
+    assert dist["segments"] == ["mid", "post", "pre", "screen"]
     assert torch.equal(dist["flat"], single.global_arena.data.cpu())
     assert dist["loss"] == reps[-1].agg_metrics["loss"]
 
@@ -79,12 +81,12 @@ comm = Communicator.from_env()          # nccl (= RCCL) on cuda:0, group forced 
 assert comm.backend == "nccl" and comm.group is not None and not comm._single
 cfg = dict({cfg!r}, reduce_algo={algo!r})
 eng = FederatedEngine(EngineConfig(**cfg), comm=comm)
-reps = eng.run(2)
+reps = eng.run(4)
 comm.barrier()
 t = comm.max_over_ranks(1.5)
 torch.cuda.synchronize()
-torch.save({{"flat": eng.global_arena.data.cpu(), "loss": reps[-1].agg_metrics["loss"], "max": t}},
-           {out!r})
+torch.save({{"flat": eng.global_arena.data.cpu(), "loss": reps[-1].agg_metrics["loss"], "max": t,
+            "segments": sorted(eng._segment_graphs)}}, {out!r})
 comm.finish(0)
 """
 
@@ -106,8 +108,12 @@ def test_rccl_collectives_single_rank_rehearsal(tmp_path, algo):
     got = torch.load(out, weights_only=True)
     torch.cuda.set_device(0)
     single = FederatedEngine(EngineConfig(**CFG), comm=Communicator(device=torch.device("cuda", 0)))
-    reps = single.run(2)
+    reps = single.run(4)
     assert got["max"] == 1.5
+    # the device work between the eager collectives was replayed from graphs (recorded in
+    # the second round, replayed in rounds 2-4)
+    assert got["segments"] == (["mid", "post", "pre", "screen"] if algo == "ordered"
+                               else ["post", "pre", "screen"])
     torch.testing.assert_close(got["flat"], single.global_arena.data.cpu(), rtol=0, atol=0)
     assert got["loss"] == pytest.approx(reps[-1].agg_metrics["loss"], rel=1e-6)
 
