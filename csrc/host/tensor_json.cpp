@@ -17,6 +17,7 @@
 #include <charconv>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <utility>
@@ -96,31 +97,79 @@ char* encode_fast(char* p, const float*& data, const long* shape, int ndim) {
     return p;
 }
 
+// Worker threads of the parallel paths: min(hardware threads, 8), or NANOFED_JSON_THREADS
+// (1 switches the parallel paths off).  Read once.
+int codec_threads() {
+    static const int cached = [] {
+        if (const char* env = std::getenv("NANOFED_JSON_THREADS")) {
+            const long v = std::strtol(env, nullptr, 10);
+            if (v >= 1) return static_cast<int>(v > 64 ? 64 : v);
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return static_cast<int>(hw == 0 ? 4 : (hw > 8 ? 8 : hw));
+    }();
+    return cached;
+}
+
+// Largest text the parallel decoder takes (it holds about five times the text in
+// buffers of its own; the bodies come from the network): NANOFED_JSON_PARALLEL_MAX_MB,
+// 256 MB by default.  Longer texts are parsed by the sequential reader, in place.
+long parallel_decode_limit() {
+    static const long cached = [] {
+        long mb = 256;
+        if (const char* env = std::getenv("NANOFED_JSON_PARALLEL_MAX_MB")) {
+            const long v = std::strtol(env, nullptr, 10);
+            if (v >= 0) mb = v;
+        }
+        return mb << 20;
+    }();
+    return cached;
+}
+
+// Joins whatever was started, also when starting the next thread throws.
+struct JoinAll {
+    std::vector<std::thread>& pool;
+    ~JoinAll() {
+        for (auto& th : pool)
+            if (th.joinable()) th.join();
+    }
+};
+
 // Large tensors: the rows of the outermost dimension are cut into contiguous ranges, one
 // per thread; every thread writes its rows (", " between them) into a buffer of its own
 // and the pieces are joined.  The text is the same as the single-threaded one.
-long encode_parallel(char* out, const float* data, const long* shape, int ndim, int threads) {
+// Returns the bytes written, or -1 when buffers or threads could not be had (the caller
+// then encodes sequentially); never throws.
+long encode_parallel(char* out, const float* data, const long* shape, int ndim, int threads) try {
     const long rows = shape[0];
     long row_numel = 1, row_lists = 0;
     for (int i = 1; i < ndim; ++i) { row_lists += row_numel; row_numel *= shape[i]; }
     const long row_bound = row_numel * 17 + row_lists * 4 + 8;
     std::vector<std::vector<char>> piece(threads);
     std::vector<long> used(threads, 0);
-    std::vector<std::thread> pool;
+    // (the buffers before the threads: an allocation that fails is caught here, not in a
+    // thread, where it would end the process)
     for (int t = 0; t < threads; ++t) {
         const long r0 = rows * t / threads, r1 = rows * (t + 1) / threads;
-        pool.emplace_back([&, t, r0, r1] {
-            piece[t].resize(static_cast<size_t>((r1 - r0) * row_bound + 8));
-            char* p = piece[t].data();
-            const float* cursor = data + r0 * row_numel;
-            for (long r = r0; r < r1; ++r) {
-                if (r != r0) { *p++ = ','; *p++ = ' '; }
-                p = encode_fast(p, cursor, shape + 1, ndim - 1);
-            }
-            used[t] = p - piece[t].data();
-        });
+        piece[t].resize(static_cast<size_t>((r1 - r0) * row_bound + 8));
     }
-    for (auto& th : pool) th.join();
+    {
+        std::vector<std::thread> pool;
+        JoinAll guard{pool};
+        pool.reserve(static_cast<size_t>(threads));
+        for (int t = 0; t < threads; ++t) {
+            const long r0 = rows * t / threads, r1 = rows * (t + 1) / threads;
+            pool.emplace_back([&, t, r0, r1]() noexcept {
+                char* p = piece[t].data();
+                const float* cursor = data + r0 * row_numel;
+                for (long r = r0; r < r1; ++r) {
+                    if (r != r0) { *p++ = ','; *p++ = ' '; }
+                    p = encode_fast(p, cursor, shape + 1, ndim - 1);
+                }
+                used[t] = p - piece[t].data();
+            });
+        }
+    }
     char* p = out;
     *p++ = '[';
     bool first = true;
@@ -133,6 +182,8 @@ long encode_parallel(char* out, const float* data, const long* shape, int ndim, 
     }
     *p++ = ']';
     return p - out;
+} catch (...) {
+    return -1;
 }
 
 // Exact powers of ten in double: 10^0 .. 10^22.
@@ -259,7 +310,7 @@ struct Reader {
 // false when the text is not of that plain form (the caller parses it sequentially, which
 // also produces the error for malformed input).
 bool decode_rows_parallel(const char* text, const char* end, float* out, long cap, long* count_out,
-                          long* rows_out, long* cols_out, const char** after, int threads) {
+                          long* rows_out, long* cols_out, const char** after, int threads) try {
     auto skip_ws = [&](const char* p) {
         while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
         return p;
@@ -285,26 +336,35 @@ bool decode_rows_parallel(const char* text, const char* end, float* out, long ca
     std::vector<std::vector<float>> piece(threads);
     std::vector<long> counts(threads, 0), cols(threads, -1);
     std::vector<char> bad(threads, 0);
-    std::vector<std::thread> pool;
+    // (the buffers before the threads: a failed allocation is caught here and the caller
+    // falls back to the sequential reader)
     for (int t = 0; t < threads; ++t) {
         const long i0 = nrows * t / threads, i1 = nrows * (t + 1) / threads;
-        pool.emplace_back([&, t, i0, i1] {
-            const long bytes = rows[i1 - 1].second - rows[i0].first;
-            piece[t].resize(static_cast<size_t>(bytes / 2 + 2));
-            Reader r{rows[i0].first, rows[i0].second, piece[t].data(), static_cast<long>(piece[t].size())};
-            for (int i = 0; i < 8; ++i) { r.seen[i] = false; r.shape[i] = 0; }
-            for (long i = i0; i < i1; ++i) {
-                r.p = rows[i].first;
-                r.end = rows[i].second;
-                r.value(1);
-                if (r.fail || r.p != rows[i].second) { bad[t] = 1; return; }
-            }
-            counts[t] = r.count;
-            cols[t] = r.seen[1] ? r.shape[1] : 0;
-            if (r.max_depth > 2) bad[t] = 1;
-        });
+        const long bytes = rows[i1 - 1].second - rows[i0].first;
+        piece[t].resize(static_cast<size_t>(bytes / 2 + 2));
     }
-    for (auto& th : pool) th.join();
+    {
+        std::vector<std::thread> pool;
+        JoinAll guard{pool};
+        pool.reserve(static_cast<size_t>(threads));
+        for (int t = 0; t < threads; ++t) {
+            const long i0 = nrows * t / threads, i1 = nrows * (t + 1) / threads;
+            pool.emplace_back([&, t, i0, i1]() noexcept {
+                Reader r{rows[i0].first, rows[i0].second, piece[t].data(),
+                         static_cast<long>(piece[t].size())};
+                for (int i = 0; i < 8; ++i) { r.seen[i] = false; r.shape[i] = 0; }
+                for (long i = i0; i < i1; ++i) {
+                    r.p = rows[i].first;
+                    r.end = rows[i].second;
+                    r.value(1);
+                    if (r.fail || r.p != rows[i].second) { bad[t] = 1; return; }
+                }
+                counts[t] = r.count;
+                cols[t] = r.seen[1] ? r.shape[1] : 0;
+                if (r.max_depth > 2) bad[t] = 1;
+            });
+        }
+    }
     long total = 0;
     for (int t = 0; t < threads; ++t) {
         if (bad[t] || cols[t] != cols[0]) return false;
@@ -322,6 +382,8 @@ bool decode_rows_parallel(const char* text, const char* end, float* out, long ca
     *cols_out = cols[0];
     *after = p;
     return true;
+} catch (...) {
+    return false;  // no memory / no threads: the sequential reader takes over
 }
 
 }  // namespace
@@ -344,9 +406,11 @@ long nf_json_encode_f32(const float* data, const long* shape, int ndim,
     if (cap >= numel * 17 + lists * 4 + 8) {
         // worth a few threads from about a quarter of a million numbers on
         if (ndim >= 2 && numel >= (1L << 18) && shape[0] >= 8) {
-            unsigned hw = std::thread::hardware_concurrency();
-            int threads = static_cast<int>(hw == 0 ? 4 : (hw > 8 ? 8 : hw));
-            if (threads > 1) return encode_parallel(out, data, shape, ndim, threads);
+            const int threads = codec_threads();
+            if (threads > 1) {
+                const long n = encode_parallel(out, data, shape, ndim, threads);
+                if (n >= 0) return n;
+            }
         }
         return encode_fast(out, cursor, shape, ndim) - out;
     }
@@ -365,9 +429,9 @@ long nf_json_encode_f32(const float* data, const long* shape, int ndim,
 // there and whatever follows is left to the caller.
 long nf_json_decode_f32(const char* text, long len, float* out, long cap,
                         long* shape_out, int* ndim_out, long* consumed_out) {
-    if (len >= (1L << 21)) {  // worth a few threads from a couple of megabytes on
-        unsigned hw = std::thread::hardware_concurrency();
-        const int threads = static_cast<int>(hw == 0 ? 4 : (hw > 8 ? 8 : hw));
+    // worth a few threads from a couple of megabytes on (up to parallel_decode_limit())
+    if (len >= (1L << 21) && len <= parallel_decode_limit()) {
+        const int threads = codec_threads();
         long count = 0, rows = 0, cols = 0;
         const char* after = nullptr;
         if (threads > 1 && decode_rows_parallel(text, text + len, out, cap, &count, &rows, &cols,
