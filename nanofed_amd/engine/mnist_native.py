@@ -294,13 +294,14 @@ class NativeBuffers:
         # (micro-batches: the gradients are added up in the gradient arena first)
         c.fuse_sgd = 1 if (train and fuse_sgd and micro == 1) else 0
         c.micro = micro
-        # one or two clients on the GPU: the three backward kernels that only need what
-        # fc1_dgrad left behind share one launch (one client 69.0 -> 72.2 rounds/s, two
-        # clients 71.5 -> 74.5; neutral with four, -3 % with eight, where four chains
-        # already fill the chip).
+        # one client on the GPU: the three backward kernels that only need what fc1_dgrad
+        # left behind share one launch (69.0 -> 72.2 rounds/s at the time).  Two clients
+        # train as two concurrent chains, which fill the gaps of each other already: 74.0
+        # rounds/s with the pair launch against 71.5 with the triple (alternating runs on
+        # one box); neutral with four, -3 % with eight.
         # NANOFED_MNIST_TRIPLE=0|1 overrides (measurements).
         triple = os.environ.get("NANOFED_MNIST_TRIPLE")
-        c.bwd_triple = int(triple == "1") if triple in ("0", "1") else int(total <= 2)
+        c.bwd_triple = int(triple == "1") if triple in ("0", "1") else int(total <= 1)
         if invariant:
             c.bwd_triple = 0
         c.ntotal = self.ntotal.data_ptr() if (train and (micro > 1 or cfg is not None

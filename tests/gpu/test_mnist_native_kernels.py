@@ -438,10 +438,10 @@ def test_three_backward_kernels_in_one_launch_train_the_same_model(monkeypatch, 
         outs.append((eng.global_arena.data.clone(), [r.agg_metrics for r in reps]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
-    # the default: on with one or two clients on the GPU, off otherwise
+    # the default: on with one client on the GPU, off otherwise
     monkeypatch.delenv("NANOFED_MNIST_TRIPLE")
     eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
-    assert eng.trainer.buf.ctx.bwd_triple == int(clients <= 2)
+    assert eng.trainer.buf.ctx.bwd_triple == int(clients <= 1)
 
 
 def test_make_streams_returns_usable_streams():
