@@ -174,8 +174,10 @@ class ArenaStateDict(dict):
             seg = host[s.offset : s.offset + s.numel]
             inv = self.layout.inv_perms.get(s.name)
             if inv is not None:
-                seg = seg[inv.to(seg.device)]
-            out[s.name] = seg.view(s.shape).to(s.dtype).clone()
+                seg = torch.take(seg, inv.to(seg.device))  # a new tensor already
+                out[s.name] = seg.view(s.shape) if s.dtype == seg.dtype else seg.view(s.shape).to(s.dtype)
+            else:
+                out[s.name] = seg.view(s.shape).to(s.dtype, copy=True)
         return out
 
 

@@ -53,12 +53,23 @@ def _version_sort_key(version_id: str) -> tuple[str, str, int, str]:
     return (m.group(1), m.group(2), int(m.group(3)), version_id)
 
 
+def _owns_storage(t: torch.Tensor) -> bool:
+    """True when ``t`` is a contiguous CPU tensor that fills its storage: saving it writes
+    exactly its bytes (a view into a larger buffer would drag the whole buffer along)."""
+    return (t.device.type == "cpu" and t.is_contiguous() and t.storage_offset() == 0
+            and t.untyped_storage().nbytes() == t.numel() * t.element_size())
+
+
 def _cpu_state(model: ModelProtocol) -> dict[str, torch.Tensor]:
-    return {
-        k: v.detach().to("cpu").contiguous().clone()
-        if isinstance(v, torch.Tensor) else v
-        for k, v in model.state_dict().items()
-    }
+    """The state to save: detached host tensors, each with a storage of its own (copied
+    only where that is not already the case)."""
+    out = {}
+    for k, v in model.state_dict().items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach()
+            v = v if _owns_storage(v) else v.to("cpu").contiguous().clone()
+        out[k] = v
+    return out
 
 
 class ModelManager:
