@@ -15,11 +15,15 @@
 // Structure: one workgroup of 8 waves per CU and output tile.  K advances in steps
 // of 64 through a ring of LDS stages that is filled by LDS-DMA (global_load_lds,
 // 16 bytes per lane, no registers, no ds_write): the loads of a later K step are
-// issued before the MFMA groups of the current one, each wave waits only for its
-// own loads of the step it is about to read (a counted s_waitcnt vmcnt) and one
-// barrier per K step both publishes that step and frees the stage the next loads
-// go into.  A DMA piece (1 KiB per wave) costs its wave some 60 or more issue
-// cycles, so the MFMA work per piece decides the speed: three tile geometries,
+// issued one piece at a time between the MFMAs of the current one, each wave waits
+// only for its own loads of the step it is about to read (a counted s_waitcnt
+// vmcnt) and one barrier per K step both publishes that step and frees the stage
+// the next loads go into.  A DMA piece (1 KiB per wave) costs its wave about 60 issue
+// cycles among bare MFMAs and two to three times that beside a burst of LDS reads
+// (neither the DMA latency nor the barrier is what costs time: a build that never
+// waited for either ran at the same speed, one without DMAs at 1.6-1.7 PFLOP/s), so
+// where a piece is issued and the MFMA work per piece decide the speed: three tile
+// geometries,
 //   256 x 256 (wave 128 x 64, 4 MFMAs per piece, 2 stages)   large outputs
 //   256 x 128 (wave  64 x 64, 2.7 MFMAs per piece, 3 stages)
 //   128 x 128 (wave  64 x 32, 2 MFMAs per piece, 4 stages)   few output tiles
@@ -51,6 +55,7 @@
 // rows.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "nf_device.h"
@@ -294,22 +299,96 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
         step_half(cur, 0);
         step_half(cur, 1);
     };
-    // first (part 0) or second (part 1) half of this wave's DMAs of one K step
-    auto issue_part = [&](int kt, int stage, int part) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p)
-            if ((p & 1) == part || PA == 1)
-                if (PA > 1 || part == 0)
-                    dma16(g.A + (srca[p] + kt * stepa), dsta + stage * G::STAGE + p * 1024);
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            if ((p & 1) == part || PB == 1)
-                if (PB > 1 || part == 1)
-                    dma16(g.B + (srcb[p] + kt * stepb), dstb + stage * G::STAGE + p * 1024);
+    // one DMA piece of the K step (A pieces first, then B pieces)
+    auto issue_piece = [&](int kt, int stage, int p) {
+        if (p < PA) dma16(g.A + (srca[p] + kt * stepa), dsta + stage * G::STAGE + p * 1024);
+        else dma16(g.B + (srcb[p - PA] + kt * stepb), dstb + stage * G::STAGE + (p - PA) * 1024);
     };
     auto issue_all = [&](int kt, int stage) {
-        issue_part(kt, stage, 0);
-        issue_part(kt, stage, 1);
+#pragma unroll
+        for (int p = 0; p < PA + PB; ++p) issue_piece(kt, stage, p);
+    };
+    // a quarter step whose share of the DMA pieces is issued between its MFMAs
+    auto step_quarter_dma = [&](int cur, auto S, int kt, int stage) {
+        constexpr int sq = decltype(S)::value;
+        constexpr int P = PA + PB, lo = sq * P / 4, hi = (sq + 1) * P / 4, NM = RM * RN;
+        const char* sa = smem + cur * G::STAGE;
+        const char* sb = sa + G::TILE_A;
+        bf16x8 af[RM], bfr[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            const int r0 = wm * (BM / G::WM) + i * 32;
+            af[i] = *reinterpret_cast<const bf16x8*>(sa + kc_off(r0 + n, 2 * sq + h));
+        }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int c0 = wn * (BN / G::WN) + j * 32;
+            bfr[j] = *reinterpret_cast<const bf16x8*>(sb + kc_off(c0 + n, 2 * sq + h));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+                const int idx = i * RN + j;
+                if (idx == 0 && hi > lo) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(kt, stage, lo);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (idx == NM / 2 && hi > lo + 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(kt, stage, lo + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // half a K step (two 16-deep groups) whose share of the DMA pieces is issued between
+    // its MFMAs (operands read through the transposing LDS loads)
+    auto step_half_dma = [&](int cur, auto H, int kt, int stage) {
+        constexpr int hf = decltype(H)::value;
+        constexpr int P = PA + PB, lo = hf * P / 2, hi = (hf + 1) * P / 2, NM = 2 * RM * RN;
+        constexpr int NP = hi - lo;
+        const char* sa = smem + cur * G::STAGE;
+        const char* sb = sa + G::TILE_A;
+        bf16x8 af[2][RM], bfr[2][RN];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = 2 * hf + u;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int r0 = wm * (BM / G::WM) + i * 32;
+                if (!A_KM) af[u][i] = *reinterpret_cast<const bf16x8*>(sa + kc_off(r0 + n, 2 * s + h));
+                else af[u][i] = km_frag<BM * 2>(sa, s * 16, r0, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int c0 = wn * (BN / G::WN) + j * 32;
+                if (!B_KM) bfr[u][j] = *reinterpret_cast<const bf16x8*>(sb + kc_off(c0 + n, 2 * s + h));
+                else bfr[u][j] = km_frag<BN * 2>(sb, s * 16, c0, lane);
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    acc[i][j] = mfma32(af[u][i], bfr[u][j], acc[i][j]);
+                    const int idx = (u * RM + i) * RN + j;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        if (idx == q * NM / NP) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(kt, stage, lo + q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     if (nk > 0) {
@@ -321,24 +400,21 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
         for (int t = 0; t < nk; ++t) {
             wait_vmcnt<(D - 1) * (PA + PB)>();
             __builtin_amdgcn_s_barrier();  // step t is in LDS for everybody; step t - 1 has been read
-            // The two waves of a SIMD take turns: one issues its DMAs (a few hundred issue
-            // cycles during which it feeds no MFMA) while the other multiplies, then the
-            // other way round.  (The count that wait_vmcnt relies on is per wave and the
-            // same either way.)
+            // The DMAs of step t + D are issued between the MFMAs of step t, a piece at a
+            // time: a piece costs its wave about 60 issue cycles among bare MFMAs and two to
+            // three times that next to a burst of fragment reads, and the matrix pipe keeps
+            // working on what was issued before.  (At 4096^3: 128 x 128 tile 163 -> 151 us,
+            // 256 x 128 150 -> 136 us against blocks of DMAs issued by half of the waves
+            // at a time; the loop without any DMA runs at 1.6-1.7 PFLOP/s.)
             const int kn = min(ks0 + t + D, kf1 - 1), sn = (t + D) % STAGES, cur = t % STAGES;
-            if (!A_KM && !B_KM) {
-                if (wave < 4) issue_part(kn, sn, 0);
-                step_quarter(cur, 0);
-                issue_part(kn, sn, wave < 4 ? 1 : 0);
-                step_quarter(cur, 1);
-                if (wave >= 4) issue_part(kn, sn, 1);
-                step_quarter(cur, 2);
-                step_quarter(cur, 3);
+            if constexpr (!A_KM && !B_KM) {
+                step_quarter_dma(cur, std::integral_constant<int, 0>{}, kn, sn);
+                step_quarter_dma(cur, std::integral_constant<int, 1>{}, kn, sn);
+                step_quarter_dma(cur, std::integral_constant<int, 2>{}, kn, sn);
+                step_quarter_dma(cur, std::integral_constant<int, 3>{}, kn, sn);
             } else {
-                if (wave < 4) issue_all(kn, sn);
-                step_half(cur, 0);
-                if (wave >= 4) issue_all(kn, sn);
-                step_half(cur, 1);
+                step_half_dma(cur, std::integral_constant<int, 0>{}, kn, sn);
+                step_half_dma(cur, std::integral_constant<int, 1>{}, kn, sn);
             }
         }
         wait_vmcnt<0>();

@@ -88,11 +88,15 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1)
         return int(_FORCED_GEO)
     ksteps = (K + 63) // 64
     t256 = (-(-M // 256)) * (-(-N // 256)) * batch
-    if t256 >= 192 and min(M, N) >= 2048 and not (layout == NT and N % 192 == 0 and t256 < 256):
+    # share of the last round of workgroups (one 256 x 256 tile per CU and round) that is used
+    fill256 = (t256 / 256.0) / -(-t256 // 256)
+    fits192 = layout == NT and N % 192 == 0
+    if t256 >= 192 and min(M, N) >= 2048 and not (fits192 and (t256 < 256 or fill256 < 0.95)):
         # both sides wide and 256 x 256 tiles for three quarters of the CUs or more: the big
         # tile reads the fewest operand bytes per MFMA (4096 x 3072 x 768: 29.8 us against
         # 33.7 us; the LM head's forward 371 us against 442 us).  A k-contiguous output of
-        # 192-column multiples just at that size is left to the 128 x 192 tile below.
+        # 192-column multiples is left to the 128 x 192 tile below when the big tiles would
+        # leave part of a round empty (8 x 4096 x 2304: 4.5 rounds, 131.6 against 137.3 us).
         return GEO_256
     if t256 >= 48 and ksteps >= 256 and min(M, N) >= 512:
         # a very long reduction (the LM head's input gradient, K = 50257, cut along K):
@@ -108,14 +112,16 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1)
             return GEO_256
     if layout == TN and t256 >= 224 and ksteps >= 32 and max(M, N) >= 16384 and min(M, N) >= 512:
         return GEO_256        # the LM head's weight gradient: one very long side (377 vs 408 us)
-    if t256 >= 1024 and layout == NT:
+    if t256 >= 1024 and layout == NT and not fits192:
         return GEO_256x128    # very wide outputs with a short K loop (the LM head)
     if layout == NT and N % 192 == 0:
         # k-contiguous operands may use 128 x 192 tiles: when they make about one full
         # round of workgroups (two per CU) where 128 x 128 tiles make one and a half
         t192 = (-(-M // 128)) * (N // 192) * batch
         t128 = (-(-M // 128)) * (-(-N // 128)) * batch
-        if 256 <= t192 <= 512 < t128:
+        if 256 <= t192 <= 512 < t128 or t192 >= 768:
+            # (many tiles - the launches of a group of clients: 8 x 4096 x 768 x 768 46.2
+            # against 50.6 us, x 3072 deep 156.4 against 177.7 us)
             return GEO_128x192
     return GEO_128_2
 

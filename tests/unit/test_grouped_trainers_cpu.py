@@ -60,4 +60,7 @@ def test_batched_gemm_heuristics_count_the_tiles_of_all_problems():
     # geometry: the tile count that selects the wide tiles is the batch's
     one = gemm_ops.choose_geometry(4096, 2304, 768, gemm_ops.NT)
     many = gemm_ops.choose_geometry(4096, 2304, 768, gemm_ops.NT, batch=8)
-    assert one == gemm_ops.GEO_128x192 and many == gemm_ops.GEO_256
+    assert one == gemm_ops.GEO_128x192 and many == gemm_ops.GEO_128x192
+    # 6.0 rounds of 256 x 256 tiles: the big tile; 4.5 rounds (above): 128 x 192
+    assert gemm_ops.choose_geometry(4096, 3072, 768, gemm_ops.NT, batch=8) == gemm_ops.GEO_256
+    assert gemm_ops.choose_geometry(4096, 3072, 768, gemm_ops.NN, batch=8) == gemm_ops.GEO_256
