@@ -15,7 +15,7 @@ from nanofed_amd.orchestration import (
 from nanofed_amd.server import FedAvgAggregator, ModelManager
 from nanofed_amd.trainer import PrivateTrainer, TorchTrainer, TrainingConfig
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 __all__ = [
     "HTTPClient",
