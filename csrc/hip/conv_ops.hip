@@ -20,7 +20,13 @@
 // pixel groups of 64 pixels, KSW waves sharing the k-steps of one pixel group; the
 // partial accumulators of a pixel group are summed through LDS at the end.  Deep
 // layers (few pixels, many channels) use 1 x 4 with chunks of 64 so that a layer
-// still makes >= 128 workgroups; wide layers 2 x 2 with chunks of 32.
+// still makes >= 128 workgroups; wide layers 2 x 2 with chunks of 32; launches large
+// enough for 512 workgroups of 256 pixels use 4 x 1: every wave runs all k-steps of its
+// 64 pixels, a chunk's weight slice (46 KB through registers and ds_write_b128, the
+// largest LDS cost of the kernel) is staged once for twice the pixels, there are twice
+// the MFMAs between two barriers and nothing is summed through LDS at the end
+// (8 x 64 images: 84 -> 65 us forward, 78 -> 62 us data gradient at 32x32x64;
+// 58 -> 48 us at 8x8x256, four images per tile).
 //
 // Weight gradient.  dW[oc][tap][ic] = sum over pixels dY[px][oc] * X[px + tap][ic]:
 // both operands have the reduction index (pixels) as the slow dimension in
@@ -48,9 +54,9 @@ using namespace nfd;
 namespace {
 
 constexpr int kBRows = 64 * 9;            // weight rows of an output-channel tile
-constexpr int kMaxAPieces = 5;            // 16-byte patch pieces per thread and chunk
+constexpr int kMaxAPieces = 7;            // 16-byte patch pieces per thread and chunk (at most)
 constexpr int kRedBytes = 4 * 4 * 16 * 64 * 4;  // accumulators of four waves
-constexpr int kColsumBytes = 4 * 2 * 2 * 32 * 4;  // column-sum staging behind them
+constexpr int kColsumBytes = 4 * 4 * 2 * 32 * 4;  // column-sum staging behind them
 constexpr int kFwdLdsCap = 124 * 1024;    // dynamic LDS the forward kernels may ask for
 
 // forward staging for chunks of CH input channels
@@ -60,7 +66,7 @@ struct FwdStage {
     static constexpr int kPieces = CH / 8;            // 16-byte pieces per row
     static constexpr int kBBytes = kBRows * kPitch;
     static constexpr int kBPerThread = kBRows * kPieces / 256;
-    static constexpr int kMaxPatch = kMaxAPieces * 256 / kPieces;  // 320 (CH 32), 160 (CH 64)
+    static constexpr int kMaxPatch = kMaxAPieces * 256 / kPieces;  // 448 (CH 32), 224 (CH 64)
     static constexpr int kSteps = 9 * CH / 16;        // MFMA k-steps per chunk
     // data-gradient variant: weights staged [tap][CH oc][64 ic], ic contiguous
     static constexpr int kTPitch = 64 * 2 + 32;       // transposing reads
@@ -100,11 +106,15 @@ __device__ __forceinline__ int patch_frag_byte(const ConvGeo& g, int m, int pitc
 // [g.Cin][9][g.Cout]: tap t of the launch uses the layer's tap 8 - t, and the weight
 // slice is staged with the reduction index (the layer's oc) as the slow dimension and
 // read through transposing LDS loads - no flipped copy of the weights is made.
-template <int PXW, int KSW, int CH, bool kDgrad>
+// NAP: patch pieces per thread this instantiation stages (ceil(patch pixels * pieces per
+// pixel / 256) of the shapes it is launched for): an unused one still costs its
+// predicated load and store in every chunk (5 us of 65 at 32x32x64).
+template <int PXW, int KSW, int CH, bool kDgrad, int NAP>
 __global__ void __launch_bounds__(256)
 conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
                    float* __restrict__ colsum, ConvGeo g) {
-    static_assert(PXW * KSW == 4 && KSW > 1, "four waves, k-split");
+    static_assert(PXW * KSW == 4, "four waves");
+    static_assert(NAP >= 1 && NAP <= kMaxAPieces, "named prefetch registers");
     using St = FwdStage<CH>;
     constexpr int TP = 64 * PXW;
     constexpr int kPitch = St::kPitch, kPieces = St::kPieces;
@@ -114,7 +124,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     char* s_b = smem;                 // [64 oc * 9 taps][CH ic]  (kDgrad: [9][CH][64])
     char* s_a = smem + kBRegion;      // [patch pixel][CH ic]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pw = wave % PXW, kw = wave / PXW;
+    const int pw = wave % PXW, kw = KSW == 1 ? 0 : wave / PXW;
     const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
     const int row0 = (tile * TP) >> g.logW;
     w += (tile / g.tpg) * g.wgs;  // this group's weights
@@ -124,7 +134,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
 #pragma unroll
     for (int i = 0; i < kMaxAPieces; ++i) {
         const int q = tid + i * 256, pp = q >> kLog, p = q & (kPieces - 1);
-        if (pp < g.np) {
+        if (i < NAP && pp < g.np) {
             const int src = patch_source(g, row0, pp);
             a_src[i] = src < 0 ? -1 : src + p * 8;
             a_dst[i] = nfix::conv_patch_byte(g.W, g.RI, pp, kPitch, g.rp, g.bp) + p * 16;
@@ -152,12 +162,12 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     // in scratch memory)
 #define NF_B_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) \
     X(14) X(15) X(16) X(17)
-#define NF_A_LIST(X) X(0) X(1) X(2) X(3) X(4)
+#define NF_A_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
 #define NF_DECL_B(i) uint4 pb##i = make_uint4(0u, 0u, 0u, 0u);
 #define NF_DECL_A(i) uint4 pa##i = make_uint4(0u, 0u, 0u, 0u);
     NF_B_LIST(NF_DECL_B)
     NF_A_LIST(NF_DECL_A)
-    static_assert(St::kBPerThread <= 18 && kMaxAPieces == 5, "named prefetch registers");
+    static_assert(St::kBPerThread <= 18 && kMaxAPieces == 7, "named prefetch registers");
     int chunk_off = 0;  // c * CH of the chunk being fetched
 #define NF_LOAD_B(i)                                                                      \
     if constexpr (i < St::kBPerThread) {                                                  \
@@ -174,7 +184,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
         }                                                                                 \
     }
 #define NF_LOAD_A(i)                                                                      \
-    {                                                                                     \
+    if constexpr (i < NAP) {                                                              \
         pa##i = make_uint4(0u, 0u, 0u, 0u);                                               \
         if (a_src[i] >= 0) pa##i = *reinterpret_cast<const uint4*>(x + a_src[i] + chunk_off); \
     }
@@ -188,8 +198,9 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
             *reinterpret_cast<uint4*>(s_b + row * kPitch + p * 16) = pb##i;               \
         }                                                                                 \
     }
-#define NF_STORE_A(i) \
-    if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(s_a + a_dst[i]) = pa##i;
+#define NF_STORE_A(i)   \
+    if constexpr (i < NAP) \
+        if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(s_a + a_dst[i]) = pa##i;
     NF_B_LIST(NF_LOAD_B)
     NF_A_LIST(NF_LOAD_A)
     for (int c = 0; c < nchunks; ++c) {
@@ -236,7 +247,7 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
 
     // sum the k-split partial accumulators of each pixel group, write bf16
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [wave][block mb*2+nb][reg][lane]
+    [[maybe_unused]] float* red = reinterpret_cast<float*>(smem);  // [wave][block mb*2+nb][reg][lane]
     if constexpr (KSW > 1) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -259,9 +270,13 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = 0.f;
+            if constexpr (KSW > 1) {
 #pragma unroll
-            for (int k2 = 0; k2 < KSW; ++k2)
-                v += red[(((k2 * PXW + pw) * 4 + blk) * 16 + r) * 64 + lane];
+                for (int k2 = 0; k2 < KSW; ++k2)
+                    v += red[(((k2 * PXW + pw) * 4 + blk) * 16 + r) * 64 + lane];
+            } else {
+                v = acc[mb][nb][r];  // the wave has run every k-step of its 64 pixels itself
+            }
             const bf16 vb = f2bf(v);
             dst[static_cast<long>(acc_row(r, lane)) * g.Cout] = vb;
             const float vf = bf2f(vb);
@@ -512,21 +527,33 @@ bool make_geo(int B, int H, int W, int Cin, int Cout, int tp, int max_patch, Con
     return g->np <= max_patch;
 }
 
-// forward tile choice: 128-pixel tiles (2 x 2 waves, chunks of 32 channels) while
-// they make >= 256 workgroups, else 64-pixel tiles (1 x 4 waves, chunks of 64)
+// forward tile choice: 256-pixel tiles (4 x 1 waves: every wave runs all k-steps of its 64
+// pixels, a chunk's weights are staged once for twice the pixels and nothing is summed
+// through LDS at the end) while they make >= 512 workgroups and the patch of a tile fits;
+// 128-pixel tiles (2 x 2 waves, chunks of 32 channels) while they make >= 256; else
+// 64-pixel tiles (1 x 4 waves, chunks of 64).  NANOFED_CONV_TILE256=0 leaves the first out.
 int fwd_tile_pixels(int B, int H, int W, int Cout) {
+    static const bool big = [] {
+        const char* e = getenv("NANOFED_CONV_TILE256");
+        return e == nullptr || e[0] != '0';
+    }();
     const long M = static_cast<long>(B) * H * W;
+    if (big && M % 256 == 0 && (M / 256) * (Cout / 64) >= 512 && 256 % W == 0) {
+        const int rows = 256 / W, ri = rows < H ? rows : H, ni = rows / ri;
+        if (ni * (ri + 2) * (W + 2) <= FwdStage<32>::kMaxPatch) return 256;
+    }
     return (M / 128) * (Cout / 64) >= 256 && M % 128 == 0 ? 128 : 64;
 }
 
 bool fwd_geo(int B, int H, int W, int Cin, int Cout, ConvGeo* g) {
     const int tp = fwd_tile_pixels(B, H, W, Cout);
-    const int max_patch = tp == 128 ? FwdStage<32>::kMaxPatch : FwdStage<64>::kMaxPatch;
+    const int max_patch = tp == 256 ? FwdStage<32>::kMaxPatch
+                          : 5 * 256 / (tp == 128 ? FwdStage<32>::kPieces : FwdStage<64>::kPieces);
     if (!make_geo(B, H, W, Cin, Cout, tp, max_patch, g)) return false;
-    const int pitch = tp == 128 ? FwdStage<32>::kPitch : FwdStage<64>::kPitch;
+    const int pitch = tp >= 128 ? FwdStage<32>::kPitch : FwdStage<64>::kPitch;
     nfix::conv_patch_pitches(g->W, g->logW, g->RI, g->logRI, g->NI, tp, pitch, &g->rp, &g->bp);
     // the larger of the two weight regions (forward, data gradient) beside the patch
-    const int wbytes = tp == 128 ? (FwdStage<32>::kTBBytes > FwdStage<32>::kBBytes ? FwdStage<32>::kTBBytes : FwdStage<32>::kBBytes)
+    const int wbytes = tp >= 128 ? (FwdStage<32>::kTBBytes > FwdStage<32>::kBBytes ? FwdStage<32>::kTBBytes : FwdStage<32>::kBBytes)
                                  : (FwdStage<64>::kTBBytes > FwdStage<64>::kBBytes ? FwdStage<64>::kTBBytes : FwdStage<64>::kBBytes);
     // NANOFED_CONV_PATCH_PAD=0 keeps the plain rows (for measurements)
     static const bool pad = [] {
@@ -577,22 +604,35 @@ int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int 
     bf16* yp = static_cast<bf16*>(y);
     constexpr int kLdsCap = kFwdLdsCap;
     static const int lds_ok =
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32, kDgrad>), kLdsCap) |
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64, kDgrad>), kLdsCap);
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<4, 1, 32, kDgrad, 6>), kLdsCap) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<4, 1, 32, kDgrad, 7>), kLdsCap) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32, kDgrad, 5>), kLdsCap) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64, kDgrad, 5>), kLdsCap);
     if (lds_ok != 0) return -20;
-    if (tp == 128) {
+    // patch pieces per thread of this shape (the instantiations cover 5, 6 and 7)
+    const int pieces = (g.np * (tp >= 128 ? 4 : 8) + 255) / 256;
+    if (tp >= 128) {
         using St = FwdStage<32>;
         int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.NI * g.bp;
         if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
         if (lds > kLdsCap) return -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32, kDgrad>), grid, dim3(256), lds, s, xp, wp,
-                           yp, colsum, g);
+        if (tp == 256 && pieces <= 6)
+            hipLaunchKernelGGL((conv3x3_fwd_kernel<4, 1, 32, kDgrad, 6>), grid, dim3(256), lds, s, xp,
+                               wp, yp, colsum, g);
+        else if (tp == 256 && pieces <= 7)
+            hipLaunchKernelGGL((conv3x3_fwd_kernel<4, 1, 32, kDgrad, 7>), grid, dim3(256), lds, s, xp,
+                               wp, yp, colsum, g);
+        else if (tp == 128 && pieces <= 5)
+            hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32, kDgrad, 5>), grid, dim3(256), lds, s, xp,
+                               wp, yp, colsum, g);
+        else
+            return -21;
     } else {
         using St = FwdStage<64>;
         int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.NI * g.bp;
         if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
-        if (lds > kLdsCap) return -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64, kDgrad>), grid, dim3(256), lds, s, xp, wp,
+        if (lds > kLdsCap || pieces > 5) return pieces > 5 ? -21 : -20;
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64, kDgrad, 5>), grid, dim3(256), lds, s, xp, wp,
                            yp, colsum, g);
     }
     return static_cast<int>(hipGetLastError());

@@ -19,6 +19,12 @@ SHAPES = [
     (4, 8, 16, 64, 128),
     (8, 16, 16, 128, 64),
     (2, 32, 32, 64, 64),
+    # large launches: the forward / data-gradient kernels take 256-pixel tiles (four waves
+    # of 64 pixels, no k-split) - one image band, one whole image, four images per tile
+    (128, 32, 32, 64, 64),
+    (256, 16, 16, 128, 128),
+    (512, 8, 8, 256, 256),
+    (512, 16, 16, 64, 128),
 ]
 
 
@@ -62,6 +68,16 @@ def test_forward_and_gradients(ops, shape):
     dw = ops.conv3x3_weight_grad(x, dy)
     assert dw.shape == wr.grad.shape
     assert _rel(dw, wr.grad) < 6e-3
+
+
+def test_large_launches_take_the_256_pixel_tile(ops):
+    """The tile is chosen from the number of workgroups it would make; the partial column
+    sums a following BatchNorm reads come one row per tile."""
+    tiles = lambda b, h, w, c: int(ops._fn("nf_conv3x3_fwd_tiles")(b, h, w, c))  # noqa: E731
+    assert tiles(128, 32, 32, 64) == 128 * 1024 // 256
+    assert tiles(64, 32, 32, 64) == 64 * 1024 // 128       # too few tiles of 256 pixels
+    assert tiles(512, 8, 8, 256) == 512 * 64 // 256
+    assert tiles(512, 4, 4, 512) == 512 * 16 // 128        # the patch of 16 images does not fit
 
 
 def test_weight_split_does_not_change_the_result_much(ops):
