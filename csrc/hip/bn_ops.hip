@@ -9,6 +9,7 @@
 //               2. fixed-order final sum -> mean, 1/std; running statistics
 //               3. y = relu(x * scale + shift (+ residual)), 16-byte vectors
 //   nf_bn_bwd   1. partial sums of dz and dz * xhat, where dz = dy masked by y > 0
+//                  (nf_bn_bwd_pre_g: taken from the kernel that produced dz instead)
 //               2. final sums -> d(gamma), d(beta) (fp32)
 //               3. dx = (dz - mean(dz) - xhat * mean(dz * xhat)) * gamma / std,
 //                  and d(residual) = dz
@@ -257,15 +258,23 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const bf16* dy, con
 
 // coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat); d(gamma), d(beta) are overwritten
 // (fp32, or bf16 when out_bf16 is set; group g writes ostride elements after group g - 1).
+// raw_stats (may be null): the second partial sum is that of dz * x, not of dz * xhat (the
+// partials come from the kernel that produced dz, which does not know the statistics):
+// sum dz xhat = (sum dz x - mean sum dz) / std, with this group's mean and 1/std from it.
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* partial, float* coef,
                                                            void* dgamma, void* dbeta,
                                                            int nblocks, int C, float inv_count,
-                                                           int out_bf16, long ostride) {
+                                                           int out_bf16, long ostride,
+                                                           const float* raw_stats) {
     float sb, sg;
     partial += static_cast<long>(blockIdx.y) * nblocks * 2 * C;
     coef += static_cast<long>(blockIdx.y) * 2 * C;
     const int c = final_sums(partial, nblocks, C, sb, sg);
     if (c < 0) return;
+    if (raw_stats != nullptr) {
+        const float* st = raw_stats + static_cast<long>(blockIdx.y) * 2 * C;
+        sg = (sg - st[c] * sb) * st[C + c];
+    }
     const long o = blockIdx.y * ostride + c;
     if (out_bf16) {
         static_cast<bf16*>(dbeta)[o] = f2bf(sb);
@@ -390,17 +399,21 @@ int bn_forward(const void* x, const void* res, void* y, const float* gamma, cons
     return static_cast<int>(hipGetLastError());
 }
 
+// pre (may be null): [G][pre_blocks][2][C] partial sums of dz and dz * x, written by the
+// kernel that produced dy = dz (already masked and joined: relu, dy2 and dres must be unset);
+// the pass over the pixels that would compute them is skipped.
 int bn_backward(const void* dy, const void* dy2, const void* y, const void* x, const float* stats,
                 const float* gamma, void* dx, void* dres, void* dgamma, void* dbeta,
                 float* workspace, int G, long R, int C, int relu, long pstride, int out_bf16,
-                long ostride, hipStream_t s) {
+                long ostride, hipStream_t s, const float* pre = nullptr, int pre_blocks = 0) {
     const int lpr = lanes_per_row(C);
     if (lpr == 0 || R <= 0 || G < 1 || G > 65535) return -1;
     if (!al16(dy) || !al16(x) || !al16(dx) || (relu && !al16(y)) ||
         (dres != nullptr && !al16(dres)) || (dy2 != nullptr && !al16(dy2)))
         return -2;
     if (G > 1 && (R * C) % 8 != 0) return -3;
-    const int nb = blocks_for(R, lpr);
+    if (pre != nullptr && (pre_blocks < 1 || relu || dy2 != nullptr || dres != nullptr)) return -4;
+    const int nb = pre != nullptr ? pre_blocks : blocks_for(R, lpr);
     const long rpb = (R + nb - 1) / nb;
     const size_t lds = static_cast<size_t>(8) * C * sizeof(float);
     float* coef = workspace + static_cast<long>(G) * kMaxBlocks * 2 * C;
@@ -408,14 +421,18 @@ int bn_backward(const void* dy, const void* dy2, const void* y, const void* x, c
     const bf16* dy2p = static_cast<const bf16*>(dy2);
     const bf16* yp = static_cast<const bf16*>(y);
     const bf16* xp = static_cast<const bf16*>(x);
-    if (relu)
+    if (pre != nullptr)
+        ;  // the producer of dy left the partial sums
+    else if (relu)
         hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nb, G), dim3(256), lds, s, dyp, dy2p,
                            yp, xp, stats, workspace, R, C, lpr, rpb);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nb, G), dim3(256), lds, s, dyp, dy2p,
                            yp, xp, stats, workspace, R, C, lpr, rpb);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s, workspace, coef,
-                       dgamma, dbeta, nb, C, 1.f / static_cast<float>(R), out_bf16, ostride);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s,
+                       pre != nullptr ? pre : workspace, coef, dgamma, dbeta, nb, C,
+                       1.f / static_cast<float>(R), out_bf16, ostride,
+                       pre != nullptr ? stats : static_cast<const float*>(nullptr));
     const long n8 = R * C / 8;
     const dim3 grid(grid_cap(n8, G), G), block(256);
     bf16* dxp = static_cast<bf16*>(dx);
@@ -506,6 +523,20 @@ int nf_bn_bwd_g(const void* dy, const void* dy2, const void* y, const void* x,
                 int out_bf16, long ostride, hipStream_t s) {
     return bn_backward(dy, dy2, y, x, stats, gamma, dx, dres, dgamma, dbeta, workspace, G, R, C,
                        relu, pstride, out_bf16, ostride, s);
+}
+
+// Grouped backward whose incoming gradient dz is final (masked by the ReLU, both branches
+// added) and whose per-channel partial sums exist already: pre holds [G][pre_blocks][2][C]
+// sums of dz and dz * x over disjoint pixel ranges (nf_conv3x3_dgrad_bn_g writes them).
+// Runs the fixed-order final sum and the apply pass (reads dz and x, writes dx).
+// workspace: G * (nf_bn_workspace_floats(C) + 2 * C) floats.
+int nf_bn_bwd_pre_g(const void* dz, const void* x, const float* stats, const float* gamma,
+                    void* dx, void* dgamma, void* dbeta, const float* pre, float* workspace,
+                    int G, long R, int C, int pre_blocks, long pstride, int out_bf16,
+                    long ostride, hipStream_t s) {
+    if (pre == nullptr || pre_blocks < 1 || pre_blocks > kMaxBlocks * 64) return -1;
+    return bn_backward(dz, nullptr, nullptr, x, stats, gamma, dx, nullptr, dgamma, dbeta,
+                       workspace, G, R, C, 0, pstride, out_bf16, ostride, s, pre, pre_blocks);
 }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ namespace {
 constexpr int kBRows = 64 * 9;            // weight rows of an output-channel tile
 constexpr int kMaxAPieces = 7;            // 16-byte patch pieces per thread and chunk (at most)
 constexpr int kRedBytes = 4 * 4 * 16 * 64 * 4;  // accumulators of four waves
-constexpr int kColsumBytes = 4 * 4 * 2 * 32 * 4;  // column-sum staging behind them
+constexpr int kColsumBytes = 4 * 2 * 64 * 4;    // column-sum staging behind them
 constexpr int kFwdLdsCap = 124 * 1024;    // dynamic LDS the forward kernels may ask for
 
 // forward staging for chunks of CH input channels
@@ -101,6 +101,19 @@ __device__ __forceinline__ int patch_frag_byte(const ConvGeo& g, int m, int pitc
     return nfix::conv_patch_frag_byte(g.W, g.logW, g.RI, g.logRI, m, pitch, g.rp, g.bp);
 }
 
+// What the data-gradient launch needs to finish the elementwise part of the BatchNorm
+// backward pass that consumes its result (kBnBwd): the launch then stores
+//   gz = (dX + add) where mask > 0, else 0
+// (mask: the ReLU output that followed the BatchNorm, add: the gradient from the second
+// branch that read that output, may be null) and its column sums are those of gz and
+// gz * xpre (xpre: the BatchNorm's input), which is all the BatchNorm backward needs from
+// a pass over the pixels.  All three tensors have the shape of the launch's output.
+struct BnBwdIn {
+    const bf16* mask;
+    const bf16* xpre;
+    const bf16* add;
+};
+
 // kDgrad: the launch computes a data gradient.  x is then dY, y is dX, g.Cin / g.Cout are
 // the layer's output / input channel counts, and w is the layer's weight as it is,
 // [g.Cin][9][g.Cout]: tap t of the launch uses the layer's tap 8 - t, and the weight
@@ -109,11 +122,12 @@ __device__ __forceinline__ int patch_frag_byte(const ConvGeo& g, int m, int pitc
 // NAP: patch pieces per thread this instantiation stages (ceil(patch pixels * pieces per
 // pixel / 256) of the shapes it is launched for): an unused one still costs its
 // predicated load and store in every chunk (5 us of 65 at 32x32x64).
-template <int PXW, int KSW, int CH, bool kDgrad, int NAP>
+template <int PXW, int KSW, int CH, bool kDgrad, int NAP, bool kBnBwd = false>
 __global__ void __launch_bounds__(256)
 conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
-                   float* __restrict__ colsum, ConvGeo g) {
+                   float* __restrict__ colsum, ConvGeo g, BnBwdIn fz) {
     static_assert(PXW * KSW == 4, "four waves");
+    static_assert(kDgrad || !kBnBwd, "the BatchNorm backward epilogue belongs to the data gradient");
     static_assert(NAP >= 1 && NAP <= kMaxAPieces, "named prefetch registers");
     using St = FwdStage<CH>;
     constexpr int TP = 64 * PXW;
@@ -245,8 +259,15 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
         }
     }
 
-    // sum the k-split partial accumulators of each pixel group, write bf16
+    // Epilogue.  The k-split partial accumulators of a pixel group are summed through LDS;
+    // the bf16 results are laid out [pixel][64 oc] in LDS (the main loop's regions are
+    // free by now) and leave as 16-byte pieces of whole 128-byte row segments: thread t owns
+    // channel piece t & 7 of pixels (t >> 3) + 32 i, so its column sums stay in registers
+    // over its pieces and everything that is read beside them (kBnBwd) is a 16-byte load.
     __syncthreads();
+    constexpr int kBlocksPerWave = 4 / KSW;
+    constexpr int kSP = 64 * 2 + 16;  // bytes per staged pixel
+    static_assert(TP * kSP <= kRedBytes, "the staged tile ends before the column-sum staging");
     [[maybe_unused]] float* red = reinterpret_cast<float*>(smem);  // [wave][block mb*2+nb][reg][lane]
     if constexpr (KSW > 1) {
 #pragma unroll
@@ -258,15 +279,10 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
                     red[((wave * 4 + mb * 2 + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
         __syncthreads();
     }
-    constexpr int kBlocksPerWave = 4 / KSW;
-    float cs1[kBlocksPerWave], cs2[kBlocksPerWave];  // column sums of y and y^2 (as stored)
+    bf16 vb[kBlocksPerWave][16];
 #pragma unroll
     for (int j = 0; j < kBlocksPerWave; ++j) {
-        const int blk = kw * kBlocksPerWave + j, mb = blk >> 1, nb = blk & 1;
-        const long pix0 = static_cast<long>(tile) * TP + pw * 64 + mb * 32;
-        bf16* dst = y + pix0 * g.Cout + oc0 + nb * 32 + (lane & 31);
-        cs1[j] = 0.f;
-        cs2[j] = 0.f;
+        [[maybe_unused]] const int blk = kw * kBlocksPerWave + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = 0.f;
@@ -275,38 +291,94 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
                 for (int k2 = 0; k2 < KSW; ++k2)
                     v += red[(((k2 * PXW + pw) * 4 + blk) * 16 + r) * 64 + lane];
             } else {
-                v = acc[mb][nb][r];  // the wave has run every k-step of its 64 pixels itself
+                v = acc[j >> 1][j & 1][r];  // the wave has run every k-step of its 64 pixels itself
             }
-            const bf16 vb = f2bf(v);
-            dst[static_cast<long>(acc_row(r, lane)) * g.Cout] = vb;
-            const float vf = bf2f(vb);
-            cs1[j] += vf;
-            cs2[j] = fmaf(vf, vf, cs2[j]);
+            vb[j][r] = f2bf(v);
         }
     }
-    // Per-channel sums over the tile's pixels, for a BatchNorm that follows:
-    // colsum[tile][0][oc] = sum y, colsum[tile][1][oc] = sum y^2.
-    if (colsum != nullptr) {
-        float* cs = reinterpret_cast<float*>(smem + kRedBytes);  // [wave][j][2][32]
+    if constexpr (KSW > 1) __syncthreads();  // the partial sums have been read: reuse the region
+    char* stage = smem;
 #pragma unroll
-        for (int j = 0; j < kBlocksPerWave; ++j) {
-            cs1[j] += __shfl_xor(cs1[j], 32, 64);
-            cs2[j] += __shfl_xor(cs2[j], 32, 64);
-            if (lane < 32) {
-                cs[((wave * kBlocksPerWave + j) * 2 + 0) * 32 + lane] = cs1[j];
-                cs[((wave * kBlocksPerWave + j) * 2 + 1) * 32 + lane] = cs2[j];
+    for (int j = 0; j < kBlocksPerWave; ++j) {
+        const int blk = kw * kBlocksPerWave + j, mb = blk >> 1, nb = blk & 1;
+        char* sp = stage + (pw * 64 + mb * 32) * kSP + (nb * 32 + (lane & 31)) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<bf16*>(sp + acc_row(r, lane) * kSP) = vb[j][r];
+    }
+    __syncthreads();
+
+    constexpr int kPPT = TP / 32;  // pieces per thread
+    const int chunk = tid & 7, prow = tid >> 3;
+    const long gbase = (static_cast<long>(tile) * TP + prow) * g.Cout + oc0 + chunk * 8;
+    const long gstep = 32L * g.Cout;
+    [[maybe_unused]] bf16x8 mk[kPPT], xp[kPPT], ad[kPPT];
+    if constexpr (kBnBwd) {
+        // everything the pieces need, in flight before the first is used
+#pragma unroll
+        for (int i = 0; i < kPPT; ++i) {
+            mk[i] = *reinterpret_cast<const bf16x8*>(fz.mask + gbase + i * gstep);
+            xp[i] = *reinterpret_cast<const bf16x8*>(fz.xpre + gbase + i * gstep);
+        }
+        if (fz.add != nullptr) {
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i)
+                ad[i] = *reinterpret_cast<const bf16x8*>(fz.add + gbase + i * gstep);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ad[i][k] = f2bf(0.f);
+        }
+    }
+    // column sums of the values as stored: y and y^2 (kBnBwd: gz and gz * xpre)
+    float cs1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float cs2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + (prow + 32 * i) * kSP + chunk * 16);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = bf2f(v[k]);
+            if constexpr (kBnBwd) {
+                // (the rounding of the separate kernels: the data gradient to bf16, the sum of
+                // the two branches to bf16)
+                f = bf2f(mk[i][k]) > 0.f ? f + bf2f(ad[i][k]) : 0.f;
+                o[k] = f2bf(f);
+                f = bf2f(o[k]);
+                cs2[k] = fmaf(f, bf2f(xp[i][k]), cs2[k]);
+            } else {
+                o[k] = v[k];
+                cs2[k] = fmaf(f, f, cs2[k]);
+            }
+            cs1[k] += f;
+        }
+        *reinterpret_cast<bf16x8*>(y + gbase + i * gstep) = o;
+    }
+    // Per-channel sums over the tile's pixels, for a BatchNorm that follows (kBnBwd: whose
+    // backward pass follows): colsum[tile][0][oc], colsum[tile][1][oc].
+    if (colsum != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                cs1[k] += __shfl_xor(cs1[k], off, 64);
+                cs2[k] += __shfl_xor(cs2[k], off, 64);
+            }
+        }
+        float* cs = reinterpret_cast<float*>(smem + kRedBytes);  // [wave][2][64]
+        if (lane < 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cs[(wave * 2 + 0) * 64 + lane * 8 + k] = cs1[k];
+                cs[(wave * 2 + 1) * 64 + lane * 8 + k] = cs2[k];
             }
         }
         __syncthreads();
         if (tid < 128) {
-            const int stat = tid >> 6, oc = tid & 63, nb = oc >> 5, n = oc & 31;
-            float total = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv)
-#pragma unroll
-                for (int j = 0; j < kBlocksPerWave; ++j)
-                    if ((((wv / PXW) * kBlocksPerWave + j) & 1) == nb)
-                        total += cs[((wv * kBlocksPerWave + j) * 2 + stat) * 32 + n];
+            const int stat = tid >> 6, oc = tid & 63;
+            const float total = (cs[(0 * 2 + stat) * 64 + oc] + cs[(1 * 2 + stat) * 64 + oc]) +
+                                (cs[(2 * 2 + stat) * 64 + oc] + cs[(3 * 2 + stat) * 64 + oc]);
             colsum[(static_cast<long>(tile) * 2 + stat) * g.Cout + oc0 + oc] = total;
         }
     }
@@ -585,15 +657,42 @@ int wgrad_iterations(long M, int Cin, int Cout, int G = 1) {
     return static_cast<int>(nit);
 }
 
+// One instantiation: raises its LDS limit once, launches it.
+template <int PXW, int KSW, int CH, bool kDgrad, int NAP, bool kBnBwd>
+int launch_one(dim3 grid, int lds, hipStream_t s, const bf16* x, const bf16* w, bf16* y,
+               float* colsum, const ConvGeo& g, const BnBwdIn& fz) {
+    static const int lds_ok = set_lds(
+        reinterpret_cast<const void*>(conv3x3_fwd_kernel<PXW, KSW, CH, kDgrad, NAP, kBnBwd>), kFwdLdsCap);
+    if (lds_ok != 0) return -20;
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<PXW, KSW, CH, kDgrad, NAP, kBnBwd>), grid, dim3(256), lds, s,
+                       x, w, y, colsum, g, fz);
+    return static_cast<int>(hipGetLastError());
+}
+
+// ... with or without the BatchNorm backward epilogue (data gradient only)
+template <int PXW, int KSW, int CH, bool kDgrad, int NAP>
+int launch_pick(dim3 grid, int lds, hipStream_t s, const bf16* x, const bf16* w, bf16* y,
+                float* colsum, const ConvGeo& g, const BnBwdIn* fz) {
+    if constexpr (kDgrad) {
+        if (fz != nullptr)
+            return launch_one<PXW, KSW, CH, true, NAP, true>(grid, lds, s, x, w, y, colsum, g, *fz);
+    }
+    return launch_one<PXW, KSW, CH, kDgrad, NAP, false>(grid, lds, s, x, w, y, colsum, g,
+                                                        BnBwdIn{nullptr, nullptr, nullptr});
+}
+
 // B: images of the whole launch (all groups), G groups of B / G images
 template <bool kDgrad>
 int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int H, int W,
-               int Cin, int Cout, hipStream_t s, int G = 1, long w_stride = 0) {
+               int Cin, int Cout, hipStream_t s, int G = 1, long w_stride = 0,
+               const BnBwdIn* fz = nullptr) {
     if (G < 1 || B % G != 0) return -1;
     const int tp = fwd_tile_pixels(B, H, W, Cout);
     ConvGeo g;
     if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
     if (!al16(x) || !al16(w) || !al16(y)) return -2;
+    if (fz != nullptr && (!kDgrad || fz->mask == nullptr || fz->xpre == nullptr || colsum == nullptr))
+        return -4;
     const long M = static_cast<long>(B) * H * W;
     if ((M / G) % tp != 0 || (w_stride & 7) != 0) return -3;
     g.tpg = static_cast<int>(M / G / tp);
@@ -603,12 +702,6 @@ int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int 
     const bf16* wp = static_cast<const bf16*>(w);
     bf16* yp = static_cast<bf16*>(y);
     constexpr int kLdsCap = kFwdLdsCap;
-    static const int lds_ok =
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<4, 1, 32, kDgrad, 6>), kLdsCap) |
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<4, 1, 32, kDgrad, 7>), kLdsCap) |
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<2, 2, 32, kDgrad, 5>), kLdsCap) |
-        set_lds(reinterpret_cast<const void*>(conv3x3_fwd_kernel<1, 4, 64, kDgrad, 5>), kLdsCap);
-    if (lds_ok != 0) return -20;
     // patch pieces per thread of this shape (the instantiations cover 5, 6 and 7)
     const int pieces = (g.np * (tp >= 128 ? 4 : 8) + 255) / 256;
     if (tp >= 128) {
@@ -617,25 +710,18 @@ int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int 
         if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
         if (lds > kLdsCap) return -20;
         if (tp == 256 && pieces <= 6)
-            hipLaunchKernelGGL((conv3x3_fwd_kernel<4, 1, 32, kDgrad, 6>), grid, dim3(256), lds, s, xp,
-                               wp, yp, colsum, g);
-        else if (tp == 256 && pieces <= 7)
-            hipLaunchKernelGGL((conv3x3_fwd_kernel<4, 1, 32, kDgrad, 7>), grid, dim3(256), lds, s, xp,
-                               wp, yp, colsum, g);
-        else if (tp == 128 && pieces <= 5)
-            hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 2, 32, kDgrad, 5>), grid, dim3(256), lds, s, xp,
-                               wp, yp, colsum, g);
-        else
-            return -21;
-    } else {
-        using St = FwdStage<64>;
-        int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.NI * g.bp;
-        if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
-        if (lds > kLdsCap || pieces > 5) return pieces > 5 ? -21 : -20;
-        hipLaunchKernelGGL((conv3x3_fwd_kernel<1, 4, 64, kDgrad, 5>), grid, dim3(256), lds, s, xp, wp,
-                           yp, colsum, g);
+            return launch_pick<4, 1, 32, kDgrad, 6>(grid, lds, s, xp, wp, yp, colsum, g, fz);
+        if (tp == 256 && pieces <= 7)
+            return launch_pick<4, 1, 32, kDgrad, 7>(grid, lds, s, xp, wp, yp, colsum, g, fz);
+        if (tp == 128 && pieces <= 5)
+            return launch_pick<2, 2, 32, kDgrad, 5>(grid, lds, s, xp, wp, yp, colsum, g, fz);
+        return -21;
     }
-    return static_cast<int>(hipGetLastError());
+    using St = FwdStage<64>;
+    int lds = (kDgrad ? St::kTBBytes : St::kBBytes) + g.NI * g.bp;
+    if (lds < kRedBytes + kColsumBytes) lds = kRedBytes + kColsumBytes;
+    if (lds > kLdsCap || pieces > 5) return pieces > 5 ? -21 : -20;
+    return launch_pick<1, 4, 64, kDgrad, 5>(grid, lds, s, xp, wp, yp, colsum, g, fz);
 }
 
 }  // namespace
@@ -755,6 +841,18 @@ int nf_conv3x3_fwd_g(const void* x, const void* w, void* y, float* colsum, int G
 int nf_conv3x3_dgrad_g(const void* dy, const void* w, void* dx, int G, int B, int H, int W,
                        int Cin, int Cout, long w_stride, hipStream_t s) {
     return launch_fwd<true>(dy, w, dx, nullptr, G * B, H, W, Cout, Cin, s, G, w_stride);
+}
+
+// The grouped data gradient with the elementwise part of the consuming BatchNorm's backward
+// pass in its epilogue: dx = (data gradient + add) where mask > 0, else 0; colsum
+// [G * tiles][2][Cin] (tiles = nf_conv3x3_fwd_tiles_g(G, B, H, W, Cin)) receives per-tile
+// sums of dx and dx * xpre per channel.  mask, xpre, add (may be null): [G * B][H][W][Cin].
+int nf_conv3x3_dgrad_bn_g(const void* dy, const void* w, void* dx, const void* mask,
+                          const void* xpre, const void* add, float* colsum, int G, int B, int H,
+                          int W, int Cin, int Cout, long w_stride, hipStream_t s) {
+    const BnBwdIn fz{static_cast<const bf16*>(mask), static_cast<const bf16*>(xpre),
+                     static_cast<const bf16*>(add)};
+    return launch_fwd<true>(dy, w, dx, colsum, G * B, H, W, Cout, Cin, s, G, w_stride, &fz);
 }
 
 long nf_conv3x3_wgrad_workspace_g(int G, int B, int H, int W, int Cin, int Cout) {

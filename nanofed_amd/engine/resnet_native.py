@@ -17,7 +17,12 @@ The trainer is explicit: no autograd, no module in the training path.
   patch gather + batched GEMM for the stem, the strided 3x3 and the 1x1 shortcuts),
   then BatchNorm (+ residual) (+ ReLU) with the statistics of each group;
 * backward in reverse, where a tensor that fed two branches receives its gradient as
-  the sum of two tensors inside the consuming BatchNorm kernel (no add kernels);
+  the sum of two tensors inside the consuming kernel (no add kernels).  Where the gradient
+  of a BatchNorm's output comes out of the 3x3 data-gradient kernel, that kernel's
+  epilogue already adds the second branch, applies the ReLU mask and leaves the
+  per-channel partial sums, so the BatchNorm backward is one final sum and one pass over
+  the pixels instead of two passes (13 of the 20 BatchNorm layers;
+  ``NANOFED_RESNET_FUSE_BN_BWD=0`` keeps the separate passes);
 * the head (global average pooling, classifier, cross-entropy, their gradients, the
   loss / accuracy accumulators) is two launches;
 * the whole step is captured once per group range into a hipGraph.
@@ -138,6 +143,7 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         self._acc3 = torch.zeros(G, 3, dtype=torch.float32, device=self.device)
         self._acc = self._acc3  # the inherited per-client path accumulates into the same rows
         self._lr = float(cfg.learning_rate)
+        self._fuse_bn_bwd = os.environ.get("NANOFED_RESNET_FUSE_BN_BWD", "1") != "0"
 
     # -- network plan ---------------------------------------------------------------------
     def _plan(self, model: ResNet18) -> tuple[_Unit, list[_Block]]:
@@ -189,7 +195,7 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
         bufs: dict = {"units": {}, "blocks": []}
-        ws_fwd = ws_bwd = ws_wgrad = slabs = 0
+        ws_fwd = ws_bwd = ws_wgrad = ws_pre = slabs = 0
         for u in self._units():
             ho, C = u.hout, u.cout
             d = {
@@ -206,6 +212,9 @@ class ResNetNativeTrainer(TorchGroupTrainer):
                 ws_fwd = max(ws_fwd, Gn * tiles * 2 * C)
                 ws_wgrad = max(ws_wgrad, go.conv3x3_wgrad_workspace(Gn, B, u.hin, u.hin, u.cin, C))
                 d["dx"] = bf(N, u.hin, u.hin, u.cin)
+                # pixel tiles per group of the data-gradient launch (its output has cin channels)
+                d["dtiles"] = go.conv3x3_tiles(Gn, B, u.hin, u.hin, u.cin)
+                ws_pre = max(ws_pre, Gn * d["dtiles"] * 2 * u.cin)
             else:
                 M = B * ho * ho
                 d["col"] = bf(N * ho * ho, u.kp)
@@ -224,6 +233,7 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             bufs["blocks"].append({"dres": bf(N, ho, ho, C)})
         bufs["ws_fwd"] = f32(max(ws_fwd, 1))
         bufs["ws_bwd"] = f32(max(ws_bwd, 1))
+        bufs["ws_pre"] = f32(max(ws_pre, 1))
         bufs["ws_wgrad"] = bf(max(ws_wgrad, 8))
         bufs["slabs"] = f32(max(slabs, 1))
         bufs["wpad"] = torch.zeros(Gn, 64, STEM_K, dtype=BF16, device=dev)
@@ -277,20 +287,37 @@ class ResNetNativeTrainer(TorchGroupTrainer):
 
     def _unit_bwd(self, u: _Unit, x: torch.Tensor | None, dy: torch.Tensor,
                   dy2: torch.Tensor | None, dres: torch.Tensor | None, relu: bool, g0: int,
-                  Gn: int, bufs: dict) -> torch.Tensor | None:
-        """Backward of BatchNorm and convolution; returns d(input) (None for the stem)."""
+                  Gn: int, bufs: dict, pre: int = 0, consumer: _Unit | None = None,
+                  add: torch.Tensor | None = None) -> torch.Tensor | None:
+        """Backward of BatchNorm and convolution; returns d(input) (None for the stem).
+
+        ``pre`` > 0: ``dy`` is the final gradient of the BatchNorm's output (masked, joined)
+        and ``bufs["ws_pre"]`` holds ``pre`` rows of partial sums per group, both left by
+        the data-gradient launch that produced it.  ``consumer``: the unit whose BatchNorm
+        output is this convolution's input; the data gradient then does that BatchNorm's
+        masking and partial sums (with ``add``, the other branch's gradient) and what is
+        returned is ``consumer``'s final gradient."""
         d = bufs["units"][u.conv]
         B, C = self.B, u.cout
         N = Gn * B
         rows = B * u.hout * u.hout
-        go.bn_bwd(dy, dy2, d["out"], d["y"], d["stats"], self._p32(g0, u.bn + ".weight"), d["dyp"],
-                  dres, self._g(g0, u.bn + ".weight"), self._g(g0, u.bn + ".bias"), bufs["ws_bwd"],
-                  Gn, rows, C, relu)
+        if pre:
+            go.bn_bwd_pre(dy, d["y"], d["stats"], self._p32(g0, u.bn + ".weight"), d["dyp"],
+                          self._g(g0, u.bn + ".weight"), self._g(g0, u.bn + ".bias"),
+                          bufs["ws_pre"], pre, bufs["ws_bwd"], Gn, rows, C)
+        else:
+            go.bn_bwd(dy, dy2, d["out"], d["y"], d["stats"], self._p32(g0, u.bn + ".weight"),
+                      d["dyp"], dres, self._g(g0, u.bn + ".weight"), self._g(g0, u.bn + ".bias"),
+                      bufs["ws_bwd"], Gn, rows, C, relu)
         w = self._w(g0, u.conv + ".weight")
         dw = self._g(g0, u.conv + ".weight")
         if d["native"]:
             go.conv3x3_wgrad(x, d["dyp"], dw, bufs["ws_wgrad"], Gn, B, u.hin, u.hin, u.cin, C)
-            go.conv3x3_dgrad(d["dyp"], w, d["dx"], Gn, B, u.hin, u.hin, u.cin, C)
+            fuse = None
+            if consumer is not None:
+                cd = bufs["units"][consumer.conv]
+                fuse = go.BnBwdFuse(cd["out"], cd["y"], add, bufs["ws_pre"])
+            go.conv3x3_dgrad(d["dyp"], w, d["dx"], Gn, B, u.hin, u.hin, u.cin, C, fuse=fuse)
             return d["dx"]
         stream = go._stream(d["dyp"])
         if u is self._stem:
@@ -340,21 +367,33 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         go.fc_grads(bufs["pooled"], bufs["dlogits"], bufs["loss_rows"], bufs["correct_rows"],
                     self._g(g0, "fc.weight"), self._g(g0, "fc.bias"), self._acc3[g0:], Gn, B, 512,
                     self.classes)
-        da, db = bufs["dhead"], None
+        # da (+ db): gradient of the block's output; pre > 0: da is final (see _unit_bwd)
+        da, db, pre = bufs["dhead"], None, 0
+        fuse = self._fuse_bn_bwd
+        units = bufs["units"]
         for bi in reversed(range(len(self._blocks))):
             blk = self._blocks[bi]
-            x_in = (bufs["units"][self._blocks[bi - 1].u2.conv]["out"] if bi > 0
-                    else bufs["units"]["conv1"]["out"])
-            o1 = bufs["units"][blk.u1.conv]["out"]
-            dres = bufs["blocks"][bi]["dres"]
-            d_o1 = self._unit_bwd(blk.u2, o1, da, db, dres, True, g0, Gn, bufs)
-            dxa = self._unit_bwd(blk.u1, x_in, d_o1, None, None, True, g0, Gn, bufs)
-            if blk.us is not None:
-                dxb = self._unit_bwd(blk.us, x_in, dres, None, None, False, g0, Gn, bufs)
+            below = self._blocks[bi - 1].u2 if bi > 0 else self._stem  # produced the block's input
+            x_in = units[below.conv]["out"]
+            o1 = units[blk.u1.conv]["out"]
+            dres = None if pre else bufs["blocks"][bi]["dres"]
+            inner = fuse and units[blk.u2.conv]["native"]
+            d_o1 = self._unit_bwd(blk.u2, o1, da, db, dres, True, g0, Gn, bufs, pre=pre,
+                                  consumer=blk.u1 if inner else None)
+            gout = da if pre else dres  # masked, joined gradient of the block's output
+            pre1 = units[blk.u2.conv]["dtiles"] if inner else 0
+            # the data gradient of u1 ends at the block's input, together with the shortcut's
+            joins = fuse and blk.us is None and units[blk.u1.conv]["native"]
+            dxa = self._unit_bwd(blk.u1, x_in, d_o1, None, None, True, g0, Gn, bufs, pre=pre1,
+                                 consumer=below if joins else None, add=gout if joins else None)
+            if joins:
+                da, db, pre = dxa, None, units[blk.u1.conv]["dtiles"]
+            elif blk.us is not None:
+                dxb = self._unit_bwd(blk.us, x_in, gout, None, None, False, g0, Gn, bufs)
+                da, db, pre = dxa, dxb, 0
             else:
-                dxb = dres
-            da, db = dxa, dxb
-        self._unit_bwd(self._stem, None, da, db, None, True, g0, Gn, bufs)
+                da, db, pre = dxa, gout, 0
+        self._unit_bwd(self._stem, None, da, db, None, True, g0, Gn, bufs, pre=pre)
         go.sgd_rows(self._arena[g0 : g0 + Gn], self._gradb[g0 : g0 + Gn],
                     self._shadow[g0 : g0 + Gn], self.layout.trainable_numel, self._lr,
                     cfg.weight_decay)

@@ -30,10 +30,12 @@ _SIGS = {
     "nf_conv3x3_fwd_tiles_g": ([I, I, I, I, I], I),
     "nf_conv3x3_fwd_g": ([P, P, P, P, I, I, I, I, I, I, L, P], I),
     "nf_conv3x3_dgrad_g": ([P, P, P, I, I, I, I, I, I, L, P], I),
+    "nf_conv3x3_dgrad_bn_g": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, P], I),
     "nf_conv3x3_wgrad_workspace_g": ([I, I, I, I, I, I], L),
     "nf_conv3x3_wgrad_g": ([P, P, P, P, I, I, I, I, I, I, L, P], I),
     "nf_bn_fwd_g": ([P, P, P, P, P, P, P, P, P, I, L, I, I, FL, FL, I, L, P], I),
     "nf_bn_bwd_g": ([P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, L, I, L, P], I),
+    "nf_bn_bwd_pre_g": ([P, P, P, P, P, P, P, P, P, I, L, I, I, L, I, L, P], I),
     "nf_bn_workspace_floats": ([I], I),
     "nf_gemm_bf16_batched": ([I, I, P, P, P, P, P, P, I, I, I, L, L, L, I, I, L, L, L, L, P], I),
     "nf_im2col": ([P, P, I, I, I, I, I, I, I, I, I, I, I, P], I),
@@ -181,19 +183,52 @@ def conv3x3_fwd(x: torch.Tensor, w: Ref, y: torch.Tensor, colsum: torch.Tensor |
     )
 
 
+@dataclass(frozen=True)
+class BnBwdFuse:
+    """What the data gradient needs to do the elementwise part of the backward pass of the
+    BatchNorm that produced the convolution's input: ``mask`` (the ReLU output after that
+    BatchNorm = the convolution's input), ``xpre`` (the BatchNorm's input), ``add`` (the
+    gradient from the second branch that read the ReLU output, or None), all of the shape
+    of ``dx``, and ``colsum`` ``[G * conv3x3_tiles(G, B, H, W, c_in), 2, c_in]`` float32 for
+    the per-tile sums of the masked gradient and of its product with ``xpre``."""
+
+    mask: torch.Tensor
+    xpre: torch.Tensor
+    add: torch.Tensor | None
+    colsum: torch.Tensor
+
+
 def conv3x3_dgrad(dy: torch.Tensor, w: Ref, dx: torch.Tensor, G: int, B: int, H: int, W: int,
-                  c_in: int, c_out: int) -> None:
+                  c_in: int, c_out: int, fuse: BnBwdFuse | None = None) -> None:
+    """dx = data gradient; with ``fuse``: dx = (data gradient + add) where mask > 0, else 0,
+    and the partial sums ``bn_bwd_pre`` takes."""
     _positive(G=G, B=B, H=H, W=W, c_in=c_in, c_out=c_out)
     # (the data gradient is the forward kernel run on dy: its "input" width is c_out)
     if not conv3x3_supported(G, B, H, W, c_out, c_in):
         raise DeviceError(f"conv3x3_dgrad: shape G={G} B={B} {H}x{W} {c_in}->{c_out} is not covered")
+    n_in = G * B * H * W * c_in
     _need(dy, "conv3x3_dgrad dy", BF16, G * B * H * W * c_out)
-    _need(dx, "conv3x3_dgrad dx", BF16, G * B * H * W * c_in)
+    _need(dx, "conv3x3_dgrad dx", BF16, n_in)
     _need_ref(w, "conv3x3_dgrad w", BF16, 9 * c_in * c_out, G)
+    if fuse is None:
+        library.check(
+            _fn("nf_conv3x3_dgrad_g")(_p(dy), w.ptr, _p(dx), G, B, H, W, c_in, c_out, w.stride,
+                                      _stream(dy)),
+            "conv3x3_dgrad_g",
+        )
+        return
+    _need(fuse.mask, "conv3x3_dgrad mask", BF16, n_in)
+    _need(fuse.xpre, "conv3x3_dgrad xpre", BF16, n_in)
+    _need(fuse.add, "conv3x3_dgrad add", BF16, n_in, optional=True)
+    _need(fuse.colsum, "conv3x3_dgrad colsum", F32, G * conv3x3_tiles(G, B, H, W, c_in) * 2 * c_in)
+    for t, what in ((fuse.mask, "mask"), (fuse.xpre, "xpre"), (fuse.add, "add")):
+        if t is not None and t.data_ptr() == dx.data_ptr():
+            raise DeviceError(f"conv3x3_dgrad: dx must not alias {what}")
     library.check(
-        _fn("nf_conv3x3_dgrad_g")(_p(dy), w.ptr, _p(dx), G, B, H, W, c_in, c_out, w.stride,
-                                  _stream(dy)),
-        "conv3x3_dgrad_g",
+        _fn("nf_conv3x3_dgrad_bn_g")(_p(dy), w.ptr, _p(dx), _p(fuse.mask), _p(fuse.xpre),
+                                     _p(fuse.add), _p(fuse.colsum), G, B, H, W, c_in, c_out,
+                                     w.stride, _stream(dy)),
+        "conv3x3_dgrad_bn_g",
     )
 
 
@@ -281,6 +316,36 @@ def bn_bwd(dy: torch.Tensor, dy2: torch.Tensor | None, y: torch.Tensor | None, x
                            _p(dx), _p(dres), dgamma.ptr, dbeta.ptr, _p(workspace), G, rows, C,
                            int(relu), gamma.stride, int(out_bf16), dgamma.stride, _stream(x)),
         "bn_bwd_g",
+    )
+
+
+def bn_bwd_pre(dz: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: Ref,
+               dx: torch.Tensor, dgamma: Ref, dbeta: Ref, pre: torch.Tensor, pre_blocks: int,
+               workspace: torch.Tensor, G: int, rows: int, C: int) -> None:
+    """Backward of ``bn_fwd`` for an incoming gradient ``dz`` that is final (ReLU mask
+    applied, branches added) and whose partial sums ``pre`` ``[G, pre_blocks, 2, C]`` (of dz
+    and dz * x over disjoint pixel ranges) were written by ``conv3x3_dgrad(fuse=...)``:
+    the fixed-order final sum and one pass that reads dz and x and writes dx."""
+    if dgamma.base.dtype != dbeta.base.dtype or dgamma.stride != dbeta.stride:
+        raise DeviceError("bn_bwd_pre: d(gamma) and d(beta) must live in the same buffer")
+    out_bf16 = dgamma.base.dtype == torch.bfloat16
+    _positive(G=G, rows=rows, C=C, pre_blocks=pre_blocks)
+    if C % 8:
+        raise DeviceError(f"bn_bwd_pre: {C} channels (a multiple of 8 is required)")
+    _need(dz, "bn_bwd_pre dz", BF16, G * rows * C)
+    _need(x, "bn_bwd_pre x", BF16, G * rows * C)
+    _need(stats, "bn_bwd_pre stats", F32, G * 2 * C)
+    _need_ref(gamma, "bn_bwd_pre gamma", F32, C, G)
+    _need(dx, "bn_bwd_pre dx", BF16, G * rows * C)
+    _need_ref(dgamma, "bn_bwd_pre d(gamma)", (BF16, F32), C, G)
+    _need_ref(dbeta, "bn_bwd_pre d(beta)", (BF16, F32), C, G)
+    _need(pre, "bn_bwd_pre partial sums", F32, G * pre_blocks * 2 * C)
+    _need(workspace, "bn_bwd_pre workspace", F32, bn_workspace_floats(G, C))
+    library.check(
+        _fn("nf_bn_bwd_pre_g")(_p(dz), _p(x), _p(stats), gamma.ptr, _p(dx), dgamma.ptr, dbeta.ptr,
+                               _p(pre), _p(workspace), G, rows, C, pre_blocks, gamma.stride,
+                               int(out_bf16), dgamma.stride, _stream(x)),
+        "bn_bwd_pre_g",
     )
 
 

@@ -131,6 +131,106 @@ def test_grouped_batchnorm_against_autograd_per_group(C, rows, relu, res, two):
         torch.testing.assert_close(params[g, 3 * C : 4 * C], 0.9 + 0.1 * var, rtol=1e-3, atol=1e-4)
 
 
+# every wave arrangement of the data-gradient kernel: 256-pixel tiles (6 and 7 patch pieces),
+# 128-pixel tiles, 64-pixel tiles
+FUSED = [(8, 64, 32, 64, 64, True), (8, 64, 8, 256, 256, False), (2, 8, 16, 128, 128, True),
+         (2, 16, 8, 256, 256, False), (2, 32, 4, 512, 512, True), (3, 8, 16, 128, 64, True)]
+
+
+@pytest.mark.parametrize("G,B,H,cin,cout,two", FUSED)
+def test_data_gradient_with_the_batchnorm_backward_epilogue(G, B, H, cin, cout, two):
+    """conv3x3_dgrad(fuse=...) + bn_bwd_pre against the separate kernels they replace
+    (conv3x3_dgrad, then bn_bwd with dy2 / ReLU mask / d(residual)) and against fp32
+    autograd of BatchNorm on the same incoming gradient."""
+    torch.manual_seed(G * 100 + H + cin)
+    N, C, rows = G * B, cin, B * H * H
+    wrow = cout * 9 * cin + 64
+    w = Ref((torch.randn(G, wrow, device=DEV) * 0.05).to(BF), 0)
+    dy = torch.randn(N, H, H, cout, device=DEV).to(BF)
+    # the BatchNorm that produced the convolution's input: x -> y (ReLU output)
+    prow = 2 * C + 64
+    params = torch.zeros(G, prow, device=DEV)
+    params[:, :C] = torch.rand(G, C, device=DEV) + 0.5
+    params[:, C : 2 * C] = torch.randn(G, C, device=DEV) * 0.1
+    gamma, beta = Ref(params, 0), Ref(params, C)
+    x = (torch.randn(N, H, H, C, device=DEV) * 2 + 0.3).to(BF)
+    y = torch.empty_like(x)
+    stats = torch.empty(G, 2, C, device=DEV)
+    ws = torch.empty(go.bn_workspace_floats(G, C), device=DEV)
+    go.bn_fwd(x, None, y, gamma, beta, None, None, stats, ws, G, rows, C, True, 0.1, 1e-5)
+    other = torch.randn_like(x) if two else None
+
+    # separate kernels
+    dx_plain = torch.empty_like(x)
+    go.conv3x3_dgrad(dy, w, dx_plain, G, B, H, H, cin, cout)
+    dxa = torch.empty_like(x)
+    dres = torch.empty_like(x)
+    ga = torch.zeros(G, prow, device=DEV, dtype=BF)
+    go.bn_bwd(dx_plain, other, y, x, stats, gamma, dxa, dres, Ref(ga, 0), Ref(ga, C), ws, G, rows,
+              C, True)
+
+    # fused
+    tiles = go.conv3x3_tiles(G, B, H, H, cin)
+    pre = torch.full((G * tiles, 2, C), float("nan"), device=DEV)
+    gz = torch.empty_like(x)
+    go.conv3x3_dgrad(dy, w, gz, G, B, H, H, cin, cout,
+                     fuse=go.BnBwdFuse(mask=y, xpre=x, add=other, colsum=pre))
+    dxb = torch.empty_like(x)
+    gb = torch.zeros(G, prow, device=DEV, dtype=BF)
+    go.bn_bwd_pre(gz, x, stats, gamma, dxb, Ref(gb, 0), Ref(gb, C), pre, tiles, ws, G, rows, C)
+
+    assert torch.isfinite(pre).all()
+    # the masked, joined gradient has the roundings of the separate path: the same bits
+    assert torch.equal(gz, dres)
+    assert bool(((gz == 0) | (y > 0)).all())
+    assert _rel(dxb, dxa) < 1e-2
+    assert _rel(gb[:, : 2 * C], ga[:, : 2 * C]) < 1e-2
+    for g in range(G):
+        sl = slice(g * B, (g + 1) * B)
+        # partial sums are sums over the group's tiles of gz and gz * x
+        gf, xf = gz[sl].float().view(-1, C), x[sl].float().view(-1, C)
+        sums = pre[g * tiles : (g + 1) * tiles].sum(0)
+        torch.testing.assert_close(sums[0], gf.sum(0), rtol=2e-3, atol=0.5)
+        torch.testing.assert_close(sums[1], (gf * xf).sum(0), rtol=2e-3, atol=0.5)
+        # fp32 autograd of the BatchNorm for the gradient gz
+        xg = xf.clone().requires_grad_(True)
+        gm = params[g, :C].clone().requires_grad_(True)
+        be = params[g, C : 2 * C].clone().requires_grad_(True)
+        F.batch_norm(xg, None, None, gm, be, training=True, eps=1e-5).backward(gf)
+        assert _rel(dxb[sl].view(-1, C), xg.grad) < 1e-2
+        assert _rel(gb[g, :C], gm.grad) < 1e-2
+        assert _rel(gb[g, C : 2 * C], be.grad) < 1e-2
+
+
+def test_fused_batchnorm_backward_trains_the_same_models(monkeypatch):
+    """The trainer with the BatchNorm backward folded into the data gradients against the
+    trainer with the separate passes: same gradients up to the order in which the
+    per-channel sums are added, same round."""
+    fused = _engine("native", graph=False, clients=2, samples=64, batch=32)
+    assert fused.trainer._fuse_bn_bwd
+    monkeypatch.setenv("NANOFED_RESNET_FUSE_BN_BWD", "0")
+    plain = _engine("native", graph=False, clients=2, samples=64, batch=32)
+    assert not plain.trainer._fuse_bn_bwd
+    rows = torch.cat([torch.arange(32, device=DEV) + int(fused.trainer.shards.offsets[k])
+                      for k in range(2)])
+    grads = []
+    for eng in (fused, plain):
+        eng.trainer.pool.broadcast_from(eng.global_arena.data)
+        loss, gb = eng.trainer.loss_and_grads(rows)
+        grads.append((loss.clone(), gb.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])  # the forward pass is the same code
+    lay = fused.trainer.layout
+    for seg in lay.segments:
+        if not seg.trainable:
+            continue
+        a = lay.view_of(grads[0][1][0], seg)
+        b = lay.view_of(grads[1][1][0], seg)
+        assert _cos(a, b) > 0.995, (seg.name, _cos(a, b))
+    ra, rb = fused.run(1), plain.run(1)
+    assert ra[0].agg_metrics["loss"] == pytest.approx(rb[0].agg_metrics["loss"], rel=2e-2)
+    assert _rel(fused.global_arena.data, plain.global_arena.data) < 0.02
+
+
 @pytest.mark.parametrize("layout,M,N,K", [(gemm_ops.NT, 1024, 128, 576), (gemm_ops.NT, 4096, 64, 32),
                                            (gemm_ops.NN, 512, 1152, 256), (gemm_ops.TN, 64, 32, 8192),
                                            (gemm_ops.TN, 512, 2304, 1024), (gemm_ops.TN, 128, 64, 4096)])
