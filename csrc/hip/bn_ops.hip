@@ -111,8 +111,24 @@ __device__ __forceinline__ int final_sums(const float* partial, int nblocks, int
     float a = 0.f, b = 0.f;
     if (c < C) {
         const int lo = (nblocks * wave) >> 2, hi = (nblocks * (wave + 1)) >> 2;
+        int k = lo;
+        // 32 loads in flight per lane: the kernel is a few round trips to memory and nothing
+        // else (a convolution leaves up to 256 partial rows per group)
+        for (; k + 15 < hi; k += 16) {
+            float va[16], vb[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                va[i] = partial[static_cast<long>(k + i) * 2 * C + c];
+                vb[i] = partial[static_cast<long>(k + i) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                a += va[i];
+                b += vb[i];
+            }
+        }
 #pragma unroll 4
-        for (int k = lo; k < hi; ++k) {
+        for (; k < hi; ++k) {
             a += partial[static_cast<long>(k) * 2 * C + c];
             b += partial[static_cast<long>(k) * 2 * C + C + c];
         }

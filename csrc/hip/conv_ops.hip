@@ -413,9 +413,13 @@ constexpr int kWgDyBytes = kWgTP * kWgPitch;  // 20480
 constexpr int kWgMaxPatch = 288;
 constexpr int kWgLds = kWgDyBytes + kWgMaxPatch * kWgPitch;  // 66560
 
+// NXP: 16-byte patch pieces per thread (ceil(patch pixels * 8 / 256) of the shapes the
+// instantiation is launched for).
+template <int NXP>
 __global__ void __launch_bounds__(256)
 conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
-                     bf16* __restrict__ part, ConvGeo g, int nit) {
+                     bf16* __restrict__ part, ConvGeo g, int nit, long slab_stride) {
+    static_assert(NXP >= 1 && NXP <= 9, "named prefetch registers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_dy = smem;               // [128 px][64 oc], pitch 160
     char* s_x = smem + kWgDyBytes;   // [patch pixel][64 ic], pitch 160
@@ -425,21 +429,29 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
     const int oc0 = (blockIdx.y / ict) * 64, ic0 = (blockIdx.y % ict) * 64;
     const int PW = g.W + 2, PR = g.RI + 2;
 
-    // patch staging plan, tile independent part: pieces tid + 256 i
-    // (band, row - 1, column - 1) packed, or -1 past the patch
-    int plan[9];
+    // Patch staging plan, the part that does not depend on the tile: piece tid + 256 i is
+    // 8 channels of patch pixel (band, pr, pc).  A tile starts at an image row boundary
+    // (row0 = tile * 128 / W counts rows over all images), and the patch pixel's source is
+    // pixel ((row0 + band RI + pr - 1) W + pc - 1) of the tensor whenever it lies inside its
+    // image - so its offset from the tile's first pixel is the same for every tile
+    // (poff), and only whether the row is inside the image has to be asked per tile:
+    //   plan = -1 past the patch, else (column inside the image) << 24 | band RI << 8 | pr
+    int plan[NXP], poff[NXP];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int q = tid + i * 256, pp = q >> 3;
+    for (int i = 0; i < NXP; ++i) {
+        const int q = tid + i * 256, pp = q >> 3, p = q & 7;
+        plan[i] = -1;
+        poff[i] = 0;
         if (pp < g.np) {
             const int band = pp / (PR * PW);
             const int rem = pp - band * PR * PW;
             const int pr = rem / PW, pc = rem - pr * PW;
-            plan[i] = (band << 16) | (pr << 8) | pc;
-        } else {
-            plan[i] = -1;
+            const int xin = (pc >= 1 && pc <= g.W) ? 1 : 0;
+            plan[i] = (xin << 24) | ((band * g.RI) << 8) | pr;
+            poff[i] = ((band * g.RI + pr - 1) * g.W + pc - 1) * g.Cin + ic0 + p * 8;
         }
     }
+    const int dyoff = (tid >> 3) * g.Cout + oc0 + (tid & 7) * 8;  // piece 0; piece i: + 32 i Cout
     // transposed-read lane geometry (see nfd::load_tr_frag)
     const int li = lane & 15, lq = li >> 2;
     const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
@@ -450,33 +462,36 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
     for (int t = 0; t < 9; ++t) acc[t] = f32x16{0};
 
     // tile t + 1 travels memory -> registers while tile t is being multiplied
-    // (named registers: an indexed array across loop iterations lands in scratch)
+    // (named registers: an indexed array across loop iterations lands in scratch).
+    // The loads are unconditional - a piece outside its image reads the tile's first
+    // pixel and is zeroed when it is stored (bit i of `inside`) - so that fetching a tile
+    // is straight-line code the compiler can spread between the MFMAs.
 #define NF_DY_LIST(X) X(0) X(1) X(2) X(3)
 #define NF_X_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define NF_DECL_DY(i) uint4 pdy##i = make_uint4(0u, 0u, 0u, 0u);
-#define NF_DECL_X(i) uint4 px##i = make_uint4(0u, 0u, 0u, 0u);
+#define NF_DECL_X(i) [[maybe_unused]] uint4 px##i = make_uint4(0u, 0u, 0u, 0u);
     NF_DY_LIST(NF_DECL_DY)
     NF_X_LIST(NF_DECL_X)
-    int ftile = blockIdx.x * nit;  // tile being fetched
-#define NF_LOAD_DY(i)                                                                     \
-    {                                                                                     \
-        const int q = tid + i * 256, pix = q >> 3, p = q & 7;                             \
-        pdy##i = *reinterpret_cast<const uint4*>(                                         \
-            dy + (static_cast<long>(ftile) * kWgTP + pix) * g.Cout + oc0 + p * 8);        \
+    const bf16* xt = x;    // first pixel of the tile being fetched
+    const bf16* dyt = dy;
+    int r0m = 0;           // its first row within the image
+    unsigned inside = 0, inside_next = 0;
+#define NF_SET_TILE(t)                                              \
+    {                                                               \
+        const long first = static_cast<long>(t) * kWgTP;           \
+        xt = x + first * g.Cin;                                     \
+        dyt = dy + first * g.Cout;                                  \
+        r0m = static_cast<int>(first >> g.logW) & (g.H - 1);        \
+        inside_next = 0;                                            \
     }
+#define NF_LOAD_DY(i) \
+    pdy##i = *reinterpret_cast<const uint4*>(dyt + dyoff + i * 32 * g.Cout);
 #define NF_LOAD_X(i)                                                                      \
-    {                                                                                     \
-        px##i = make_uint4(0u, 0u, 0u, 0u);                                               \
-        if (plan[i] >= 0) {                                                               \
-            const int p = (tid + i * 256) & 7;                                            \
-            const int band = plan[i] >> 16, pr = (plan[i] >> 8) & 255, pc = plan[i] & 255; \
-            const int grow = ((ftile * kWgTP) >> g.logW) + band * g.RI;                   \
-            const int img = grow >> g.logH, y0 = grow & (g.H - 1);                        \
-            const int yy = y0 + pr - 1, xx = pc - 1;                                      \
-            if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)                               \
-                px##i = *reinterpret_cast<const uint4*>(                                  \
-                    x + static_cast<long>((img * g.H + yy) * g.W + xx) * g.Cin + ic0 + p * 8); \
-        }                                                                                 \
+    if constexpr (i < NXP) {                                                              \
+        const int yy = ((r0m + ((plan[i] >> 8) & 0xFFFF)) & (g.H - 1)) + (plan[i] & 255) - 1; \
+        const bool ok = plan[i] >= (1 << 24) && static_cast<unsigned>(yy) < static_cast<unsigned>(g.H); \
+        inside_next |= ok ? (1u << i) : 0u;                                               \
+        px##i = *reinterpret_cast<const uint4*>(xt + (ok ? poff[i] : 0));                 \
     }
 #define NF_STORE_DY(i)                                                                    \
     {                                                                                     \
@@ -484,33 +499,44 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
         *reinterpret_cast<uint4*>(s_dy + pix * kWgPitch + p * 16) = pdy##i;               \
     }
 #define NF_STORE_X(i)                                                                     \
-    if (plan[i] >= 0) {                                                                   \
-        const int q = tid + i * 256, pp = q >> 3, p = q & 7;                              \
-        *reinterpret_cast<uint4*>(s_x + pp * kWgPitch + p * 16) = px##i;                  \
+    if constexpr (i < NXP) {                                                              \
+        if (plan[i] >= 0) {                                                               \
+            const int q = tid + i * 256, pp = q >> 3, p = q & 7;                          \
+            *reinterpret_cast<uint4*>(s_x + pp * kWgPitch + p * 16) =                     \
+                (inside >> i) & 1u ? px##i : make_uint4(0u, 0u, 0u, 0u);                  \
+        }                                                                                 \
     }
+    NF_SET_TILE(blockIdx.x * nit)
     NF_DY_LIST(NF_LOAD_DY)
     NF_X_LIST(NF_LOAD_X)
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
+        inside = inside_next;
         NF_DY_LIST(NF_STORE_DY)
         NF_X_LIST(NF_STORE_X)
+        __syncthreads();
         if (it + 1 < nit) {
-            ftile = blockIdx.x * nit + it + 1;
+            NF_SET_TILE(blockIdx.x * nit + it + 1)
             NF_DY_LIST(NF_LOAD_DY)
             NF_X_LIST(NF_LOAD_X)
         }
-        __syncthreads();
 #undef NF_DY_LIST
 #undef NF_X_LIST
 #undef NF_DECL_DY
 #undef NF_DECL_X
+#undef NF_SET_TILE
 #undef NF_LOAD_DY
 #undef NF_LOAD_X
 #undef NF_STORE_DY
 #undef NF_STORE_X
-#pragma unroll 1
-        for (int ks = 0; ks < kWgTP / 16; ++ks) {
-            const bf16x8 Afr = load_tr_frag(s_dy, kWgPitch, ks * 16, ob * 32, lane);
+        // Eight k-steps of 16 pixels, software-pipelined: the 20 transposing reads of step
+        // k + 1 (2 for the dY fragment, 18 for the nine shifted X fragments) are issued
+        // between the nine MFMAs of step k, two per MFMA (the scheduling hints below pin
+        // that order; left alone, the compiler puts each step's reads directly before its
+        // MFMAs and every step starts with a full LDS round trip).
+        bf16x8 fa[2], fb[2][9];
+        auto fetch = [&](int ks, bf16x8& A, bf16x8 (&B)[9]) {
+            A = load_tr_frag(s_dy, kWgPitch, ks * 16, ob * 32, lane);
             // the 8 pixels of this lane half: two groups of 4 consecutive pixels
             const int m0 = ks * 16 + h * 8;
             const char* r0 = xb + (patch_index(g, m0) + lq) * kWgPitch;
@@ -520,12 +546,29 @@ conv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                 const int toff = ((t / 3) * PW + (t % 3)) * kWgPitch;
                 const bf16x4 lo = lds_tr4(r0 + toff);
                 const bf16x4 hi = lds_tr4(r1 + toff);
-                const bf16x8 Bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[t] = mfma32(Afr, Bfr, acc[t]);
+                B[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        fetch(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < kWgTP / 16; ++ks) {
+            if (ks + 1 < kWgTP / 16) fetch(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = mfma32(fa[ks & 1], fb[ks & 1][t], acc[t]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);  // step 0's reads
+#pragma unroll
+        for (int ks = 0; ks + 1 < kWgTP / 16; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // two LDS reads
             }
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
     }
-    bf16* slab = part + static_cast<long>(blockIdx.x) * g.Cout * 9 * g.Cin;
+    bf16* slab = part + static_cast<long>(blockIdx.x) * slab_stride;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -787,11 +830,25 @@ int wgrad_launch(const void* x, const void* dy, void* dw, void* workspace, int B
     const int nit = wgrad_iterations(Mg, Cin, Cout, G);
     const int slabs = static_cast<int>(Mg / kWgTP / nit);  // per group
     const dim3 grid(slabs * G, (Cout / 64) * (Cin / 64));
-    static const int lds_ok = set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), kWgLds);
+    static const int lds_ok =
+        set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<6>), kWgLds) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<7>), kWgLds) |
+        set_lds(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<9>), kWgLds);
     if (lds_ok != 0) return -20;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), kWgLds, s,
-                       static_cast<const bf16*>(x), static_cast<const bf16*>(dy),
-                       static_cast<bf16*>(workspace), g, nit);
+    const bf16* xp = static_cast<const bf16*>(x);
+    const bf16* dyp = static_cast<const bf16*>(dy);
+    // one pixel range per group: its tile is the gradient itself, written in place
+    const bool direct = slabs == 1;
+    bf16* wp = static_cast<bf16*>(direct ? dw : workspace);
+    const long sstride = direct ? dw_stride : static_cast<long>(Cout) * 9 * Cin;
+    const int pieces = (g.np * 8 + 255) / 256;  // patch pieces per thread (at most 9)
+    if (pieces <= 6)
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<6>, grid, dim3(256), kWgLds, s, xp, dyp, wp, g, nit, sstride);
+    else if (pieces <= 7)
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<7>, grid, dim3(256), kWgLds, s, xp, dyp, wp, g, nit, sstride);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, grid, dim3(256), kWgLds, s, xp, dyp, wp, g, nit, sstride);
+    if (direct) return static_cast<int>(hipGetLastError());
     const long n4 = static_cast<long>(Cout) * 9 * Cin / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((n4 + 63) / 64), G),
                        dim3(256), 0, s, static_cast<const bf16*>(workspace), static_cast<bf16*>(dw),
