@@ -100,45 +100,53 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16* x, fl
     reduce_and_store(s, q, lpr, C, partial, red);
 }
 
-// Fixed-order sum of the per-workgroup partials of 64 channels: wave w adds a
-// quarter of the rows, wave 0 combines.  Returns the channel of this lane in
-// wave 0 (with the two sums), -1 for every other thread.
+// Fixed-order sum of the per-workgroup partials of kFinalCh channels: thread (rl, cl) adds
+// rows rl, rl + 16, ... of channel cl (eight loads of each statistic in flight: the kernel is
+// a few round trips to memory and nothing else - a convolution leaves up to 256 partial rows
+// per group), the 16 row lanes meet in LDS and are added pairwise in a fixed order.  Returns
+// the channel of this thread for rl == 0 (with the two sums), -1 for every other thread.
+constexpr int kFinalCh = 16;
+
 __device__ __forceinline__ int final_sums(const float* partial, int nblocks, int C, float& s0,
                                           float& s1) {
-    __shared__ float red[4][2][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    __shared__ float red[16][2][kFinalCh];
+    const int cl = threadIdx.x & (kFinalCh - 1), rl = threadIdx.x / kFinalCh;
+    const int c = blockIdx.x * kFinalCh + cl;
     float a = 0.f, b = 0.f;
     if (c < C) {
-        const int lo = (nblocks * wave) >> 2, hi = (nblocks * (wave + 1)) >> 2;
-        int k = lo;
-        // 32 loads in flight per lane: the kernel is a few round trips to memory and nothing
-        // else (a convolution leaves up to 256 partial rows per group)
-        for (; k + 15 < hi; k += 16) {
-            float va[16], vb[16];
+        const float* p = partial + c;
+        const long row = 2L * C;
+        int k = rl;
+        for (; k + 7 * 16 < nblocks; k += 8 * 16) {
+            float va[8], vb[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                va[i] = partial[static_cast<long>(k + i) * 2 * C + c];
-                vb[i] = partial[static_cast<long>(k + i) * 2 * C + C + c];
+            for (int i = 0; i < 8; ++i) {
+                va[i] = p[(k + 16 * i) * row];
+                vb[i] = p[(k + 16 * i) * row + C];
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 a += va[i];
                 b += vb[i];
             }
         }
-#pragma unroll 4
-        for (; k < hi; ++k) {
-            a += partial[static_cast<long>(k) * 2 * C + c];
-            b += partial[static_cast<long>(k) * 2 * C + C + c];
+        for (; k < nblocks; k += 16) {
+            a += p[k * row];
+            b += p[k * row + C];
         }
     }
-    red[wave][0][lane] = a;
-    red[wave][1][lane] = b;
+    red[rl][0][cl] = a;
+    red[rl][1][cl] = b;
     __syncthreads();
-    if (wave != 0 || c >= C) return -1;
-    s0 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-    s1 = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    if (rl != 0 || c >= C) return -1;
+    float t0[8], t1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        t0[i] = red[2 * i][0][cl] + red[2 * i + 1][0][cl];
+        t1[i] = red[2 * i][1][cl] + red[2 * i + 1][1][cl];
+    }
+    s0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + (t0[6] + t0[7]));
+    s1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + (t1[6] + t1[7]));
     return c;
 }
 
@@ -396,7 +404,7 @@ int bn_forward(const void* x, const void* res, void* y, const float* gamma, cons
                            static_cast<const bf16*>(x), workspace, R, C, lpr, rpb);
     }
     const float unbias = R > 1 ? static_cast<float>(R) / static_cast<float>(R - 1) : 1.f;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s, workspace,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + kFinalCh - 1) / kFinalCh, G), dim3(256), 0, s, workspace,
                        stats, running_mean, running_var, nb, C, 1.f / static_cast<float>(R),
                        unbias, momentum, eps, pstride);
     const long n8 = R * C / 8;
@@ -445,7 +453,7 @@ int bn_backward(const void* dy, const void* dy2, const void* y, const void* x, c
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nb, G), dim3(256), lds, s, dyp, dy2p,
                            yp, xp, stats, workspace, R, C, lpr, rpb);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64, G), dim3(256), 0, s,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinalCh - 1) / kFinalCh, G), dim3(256), 0, s,
                        pre != nullptr ? pre : workspace, coef, dgamma, dbeta, nb, C,
                        1.f / static_cast<float>(R), out_bf16, ostride,
                        pre != nullptr ? stats : static_cast<const float*>(nullptr));
