@@ -108,10 +108,19 @@ __device__ __forceinline__ int patch_frag_byte(const ConvGeo& g, int m, int pitc
 // branch that read that output, may be null) and its column sums are those of gz and
 // gz * xpre (xpre: the BatchNorm's input), which is all the BatchNorm backward needs from
 // a pass over the pixels.  All three tensors have the shape of the launch's output.
+// Where the BatchNorm had no residual input its ReLU output is a function of xpre alone, and
+// the mask is recomputed from xpre with the arithmetic of the kernel that wrote the output
+// (bn_apply_kernel: fma(x, sc, sh) with sc = gamma / std, sh = fma(-mean, sc, beta)) instead of
+// being read: mask == nullptr, stats [groups][2][C] (mean, 1/std), gamma / beta of group 0 with
+// pstride floats between groups.
 struct BnBwdIn {
     const bf16* mask;
     const bf16* xpre;
     const bf16* add;
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    long pstride;
 };
 
 // kDgrad: the launch computes a data gradient.  x is then dY, y is dX, g.Cin / g.Cout are
@@ -312,12 +321,23 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     const long gbase = (static_cast<long>(tile) * TP + prow) * g.Cout + oc0 + chunk * 8;
     const long gstep = 32L * g.Cout;
     [[maybe_unused]] bf16x8 mk[kPPT], xp[kPPT], ad[kPPT];
+    [[maybe_unused]] float sc[8], sh[8];
+    [[maybe_unused]] const bool remask = kBnBwd && fz.mask == nullptr;
     if constexpr (kBnBwd) {
         // everything the pieces need, in flight before the first is used
 #pragma unroll
         for (int i = 0; i < kPPT; ++i) {
-            mk[i] = *reinterpret_cast<const bf16x8*>(fz.mask + gbase + i * gstep);
             xp[i] = *reinterpret_cast<const bf16x8*>(fz.xpre + gbase + i * gstep);
+            if (!remask) mk[i] = *reinterpret_cast<const bf16x8*>(fz.mask + gbase + i * gstep);
+        }
+        if (remask) {
+            const int grp = tile / g.tpg, c0 = oc0 + chunk * 8;
+            const float* st = fz.stats + static_cast<long>(grp) * 2 * g.Cout;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sc[k] = st[g.Cout + c0 + k] * fz.gamma[grp * fz.pstride + c0 + k];
+                sh[k] = fmaf(-st[c0 + k], sc[k], fz.beta[grp * fz.pstride + c0 + k]);
+            }
         }
         if (fz.add != nullptr) {
 #pragma unroll
@@ -343,7 +363,9 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
             if constexpr (kBnBwd) {
                 // (the rounding of the separate kernels: the data gradient to bf16, the sum of
                 // the two branches to bf16)
-                f = bf2f(mk[i][k]) > 0.f ? f + bf2f(ad[i][k]) : 0.f;
+                const bool on = remask ? fmaf(bf2f(xp[i][k]), sc[k], sh[k]) > 0.f
+                                       : bf2f(mk[i][k]) > 0.f;
+                f = on ? f + bf2f(ad[i][k]) : 0.f;
                 o[k] = f2bf(f);
                 f = bf2f(o[k]);
                 cs2[k] = fmaf(f, bf2f(xp[i][k]), cs2[k]);
@@ -720,8 +742,7 @@ int launch_pick(dim3 grid, int lds, hipStream_t s, const bf16* x, const bf16* w,
         if (fz != nullptr)
             return launch_one<PXW, KSW, CH, true, NAP, true>(grid, lds, s, x, w, y, colsum, g, *fz);
     }
-    return launch_one<PXW, KSW, CH, kDgrad, NAP, false>(grid, lds, s, x, w, y, colsum, g,
-                                                        BnBwdIn{nullptr, nullptr, nullptr});
+    return launch_one<PXW, KSW, CH, kDgrad, NAP, false>(grid, lds, s, x, w, y, colsum, g, BnBwdIn{});
 }
 
 // B: images of the whole launch (all groups), G groups of B / G images
@@ -734,7 +755,9 @@ int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int 
     ConvGeo g;
     if (!fwd_geo(B, H, W, Cin, Cout, &g)) return -1;
     if (!al16(x) || !al16(w) || !al16(y)) return -2;
-    if (fz != nullptr && (!kDgrad || fz->mask == nullptr || fz->xpre == nullptr || colsum == nullptr))
+    if (fz != nullptr && (!kDgrad || fz->xpre == nullptr || colsum == nullptr)) return -4;
+    if (fz != nullptr && fz->mask == nullptr &&
+        (fz->stats == nullptr || fz->gamma == nullptr || fz->beta == nullptr))
         return -4;
     const long M = static_cast<long>(B) * H * W;
     if ((M / G) % tp != 0 || (w_stride & 7) != 0) return -3;
@@ -904,11 +927,15 @@ int nf_conv3x3_dgrad_g(const void* dy, const void* w, void* dx, int G, int B, in
 // pass in its epilogue: dx = (data gradient + add) where mask > 0, else 0; colsum
 // [G * tiles][2][Cin] (tiles = nf_conv3x3_fwd_tiles_g(G, B, H, W, Cin)) receives per-tile
 // sums of dx and dx * xpre per channel.  mask, xpre, add (may be null): [G * B][H][W][Cin].
+// mask == nullptr: the BatchNorm had no residual input and the mask is recomputed from xpre
+// (its input) with stats [G][2][Cin] (mean, 1/std) and gamma / beta (group 0's vectors,
+// pstride floats between groups).
 int nf_conv3x3_dgrad_bn_g(const void* dy, const void* w, void* dx, const void* mask,
-                          const void* xpre, const void* add, float* colsum, int G, int B, int H,
-                          int W, int Cin, int Cout, long w_stride, hipStream_t s) {
+                          const void* xpre, const void* add, float* colsum, const float* stats,
+                          const float* gamma, const float* beta, long pstride, int G, int B,
+                          int H, int W, int Cin, int Cout, long w_stride, hipStream_t s) {
     const BnBwdIn fz{static_cast<const bf16*>(mask), static_cast<const bf16*>(xpre),
-                     static_cast<const bf16*>(add)};
+                     static_cast<const bf16*>(add), stats, gamma, beta, pstride};
     return launch_fwd<true>(dy, w, dx, colsum, G * B, H, W, Cout, Cin, s, G, w_stride, &fz);
 }
 

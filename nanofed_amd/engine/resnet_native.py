@@ -144,6 +144,8 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         self._acc = self._acc3  # the inherited per-client path accumulates into the same rows
         self._lr = float(cfg.learning_rate)
         self._fuse_bn_bwd = os.environ.get("NANOFED_RESNET_FUSE_BN_BWD", "1") != "0"
+        # recompute the ReLU mask of a BatchNorm without residual from its input (else read it)
+        self._remask = os.environ.get("NANOFED_RESNET_REMASK", "1") != "0"
 
     # -- network plan ---------------------------------------------------------------------
     def _plan(self, model: ResNet18) -> tuple[_Unit, list[_Block]]:
@@ -288,7 +290,7 @@ class ResNetNativeTrainer(TorchGroupTrainer):
     def _unit_bwd(self, u: _Unit, x: torch.Tensor | None, dy: torch.Tensor,
                   dy2: torch.Tensor | None, dres: torch.Tensor | None, relu: bool, g0: int,
                   Gn: int, bufs: dict, pre: int = 0, consumer: _Unit | None = None,
-                  add: torch.Tensor | None = None) -> torch.Tensor | None:
+                  add: torch.Tensor | None = None, plain: bool = False) -> torch.Tensor | None:
         """Backward of BatchNorm and convolution; returns d(input) (None for the stem).
 
         ``pre`` > 0: ``dy`` is the final gradient of the BatchNorm's output (masked, joined)
@@ -296,7 +298,8 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         the data-gradient launch that produced it.  ``consumer``: the unit whose BatchNorm
         output is this convolution's input; the data gradient then does that BatchNorm's
         masking and partial sums (with ``add``, the other branch's gradient) and what is
-        returned is ``consumer``'s final gradient."""
+        returned is ``consumer``'s final gradient; ``plain``: that BatchNorm had no
+        residual input (its ReLU mask is recomputed from its input instead of read)."""
         d = bufs["units"][u.conv]
         B, C = self.B, u.cout
         N = Gn * B
@@ -316,7 +319,12 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             fuse = None
             if consumer is not None:
                 cd = bufs["units"][consumer.conv]
-                fuse = go.BnBwdFuse(cd["out"], cd["y"], add, bufs["ws_pre"])
+                if plain and self._remask:
+                    fuse = go.BnBwdFuse(None, cd["y"], add, bufs["ws_pre"], cd["stats"],
+                                        self._p32(g0, consumer.bn + ".weight"),
+                                        self._p32(g0, consumer.bn + ".bias"))
+                else:
+                    fuse = go.BnBwdFuse(cd["out"], cd["y"], add, bufs["ws_pre"])
             go.conv3x3_dgrad(d["dyp"], w, d["dx"], Gn, B, u.hin, u.hin, u.cin, C, fuse=fuse)
             return d["dx"]
         stream = go._stream(d["dyp"])
@@ -379,13 +387,14 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             dres = None if pre else bufs["blocks"][bi]["dres"]
             inner = fuse and units[blk.u2.conv]["native"]
             d_o1 = self._unit_bwd(blk.u2, o1, da, db, dres, True, g0, Gn, bufs, pre=pre,
-                                  consumer=blk.u1 if inner else None)
+                                  consumer=blk.u1 if inner else None, plain=True)
             gout = da if pre else dres  # masked, joined gradient of the block's output
             pre1 = units[blk.u2.conv]["dtiles"] if inner else 0
             # the data gradient of u1 ends at the block's input, together with the shortcut's
             joins = fuse and blk.us is None and units[blk.u1.conv]["native"]
             dxa = self._unit_bwd(blk.u1, x_in, d_o1, None, None, True, g0, Gn, bufs, pre=pre1,
-                                 consumer=below if joins else None, add=gout if joins else None)
+                                 consumer=below if joins else None, add=gout if joins else None,
+                                 plain=below is self._stem)
             if joins:
                 da, db, pre = dxa, None, units[blk.u1.conv]["dtiles"]
             elif blk.us is not None:

@@ -30,7 +30,7 @@ _SIGS = {
     "nf_conv3x3_fwd_tiles_g": ([I, I, I, I, I], I),
     "nf_conv3x3_fwd_g": ([P, P, P, P, I, I, I, I, I, I, L, P], I),
     "nf_conv3x3_dgrad_g": ([P, P, P, I, I, I, I, I, I, L, P], I),
-    "nf_conv3x3_dgrad_bn_g": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, P], I),
+    "nf_conv3x3_dgrad_bn_g": ([P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, L, P], I),
     "nf_conv3x3_wgrad_workspace_g": ([I, I, I, I, I, I], L),
     "nf_conv3x3_wgrad_g": ([P, P, P, P, I, I, I, I, I, I, L, P], I),
     "nf_bn_fwd_g": ([P, P, P, P, P, P, P, P, P, I, L, I, I, FL, FL, I, L, P], I),
@@ -190,12 +190,19 @@ class BnBwdFuse:
     BatchNorm = the convolution's input), ``xpre`` (the BatchNorm's input), ``add`` (the
     gradient from the second branch that read the ReLU output, or None), all of the shape
     of ``dx``, and ``colsum`` ``[G * conv3x3_tiles(G, B, H, W, c_in), 2, c_in]`` float32 for
-    the per-tile sums of the masked gradient and of its product with ``xpre``."""
+    the per-tile sums of the masked gradient and of its product with ``xpre``.
 
-    mask: torch.Tensor
+    ``mask=None`` with ``stats`` ``[G, 2, c_in]``, ``gamma`` and ``beta`` (float32 ``Ref``s):
+    the BatchNorm had no residual input, and the kernel recomputes the sign of its output
+    from ``xpre`` instead of reading the output."""
+
+    mask: torch.Tensor | None
     xpre: torch.Tensor
     add: torch.Tensor | None
     colsum: torch.Tensor
+    stats: torch.Tensor | None = None
+    gamma: Ref | None = None
+    beta: Ref | None = None
 
 
 def conv3x3_dgrad(dy: torch.Tensor, w: Ref, dx: torch.Tensor, G: int, B: int, H: int, W: int,
@@ -217,7 +224,17 @@ def conv3x3_dgrad(dy: torch.Tensor, w: Ref, dx: torch.Tensor, G: int, B: int, H:
             "conv3x3_dgrad_g",
         )
         return
-    _need(fuse.mask, "conv3x3_dgrad mask", BF16, n_in)
+    null, pstride = c_void_p(0), 0
+    stats = gamma = beta = null
+    if fuse.mask is None:
+        _need(fuse.stats, "conv3x3_dgrad stats", F32, G * 2 * c_in)
+        _need_ref(fuse.gamma, "conv3x3_dgrad gamma", F32, c_in, G)
+        _need_ref(fuse.beta, "conv3x3_dgrad beta", F32, c_in, G)
+        if fuse.gamma.stride != fuse.beta.stride:
+            raise DeviceError("conv3x3_dgrad: gamma and beta must be rows of one arena")
+        stats, gamma, beta, pstride = _p(fuse.stats), fuse.gamma.ptr, fuse.beta.ptr, fuse.gamma.stride
+    else:
+        _need(fuse.mask, "conv3x3_dgrad mask", BF16, n_in)
     _need(fuse.xpre, "conv3x3_dgrad xpre", BF16, n_in)
     _need(fuse.add, "conv3x3_dgrad add", BF16, n_in, optional=True)
     _need(fuse.colsum, "conv3x3_dgrad colsum", F32, G * conv3x3_tiles(G, B, H, W, c_in) * 2 * c_in)
@@ -226,8 +243,8 @@ def conv3x3_dgrad(dy: torch.Tensor, w: Ref, dx: torch.Tensor, G: int, B: int, H:
             raise DeviceError(f"conv3x3_dgrad: dx must not alias {what}")
     library.check(
         _fn("nf_conv3x3_dgrad_bn_g")(_p(dy), w.ptr, _p(dx), _p(fuse.mask), _p(fuse.xpre),
-                                     _p(fuse.add), _p(fuse.colsum), G, B, H, W, c_in, c_out,
-                                     w.stride, _stream(dy)),
+                                     _p(fuse.add), _p(fuse.colsum), stats, gamma, beta, pstride,
+                                     G, B, H, W, c_in, c_out, w.stride, _stream(dy)),
         "conv3x3_dgrad_bn_g",
     )
 

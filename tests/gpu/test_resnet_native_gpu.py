@@ -182,6 +182,14 @@ def test_data_gradient_with_the_batchnorm_backward_epilogue(G, B, H, cin, cout, 
     assert torch.isfinite(pre).all()
     # the masked, joined gradient has the roundings of the separate path: the same bits
     assert torch.equal(gz, dres)
+    # ... and so has the variant that recomputes the mask from the BatchNorm's input
+    # (this BatchNorm has no residual input) instead of reading its output
+    pre2 = torch.full_like(pre, float("nan"))
+    gz2 = torch.empty_like(x)
+    go.conv3x3_dgrad(dy, w, gz2, G, B, H, H, cin, cout,
+                     fuse=go.BnBwdFuse(mask=None, xpre=x, add=other, colsum=pre2, stats=stats,
+                                       gamma=gamma, beta=beta))
+    assert torch.equal(gz2, gz) and torch.equal(pre2, pre)
     assert bool(((gz == 0) | (y > 0)).all())
     assert _rel(dxb, dxa) < 1e-2
     assert _rel(gb[:, : 2 * C], ga[:, : 2 * C]) < 1e-2

@@ -1,0 +1,8 @@
+# A/B: ReLU mask recomputed from the BatchNorm input (1) or read from its output (0).
+set -o pipefail
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
+for v in 1 0 1 0 1 0; do
+  echo -n "NANOFED_RESNET_REMASK=$v  "
+  NANOFED_RESNET_REMASK=$v timeout -k 10 200 python3 benchmarks/run_configs.py resnet18 --rounds 10 --warmup 3 \
+    | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['rounds_per_s'], d['train_loss'])" || exit 1
+done
