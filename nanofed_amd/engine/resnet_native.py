@@ -21,7 +21,8 @@ The trainer is explicit: no autograd, no module in the training path.
   of a BatchNorm's output comes out of the 3x3 data-gradient kernel, that kernel's
   epilogue already adds the second branch, applies the ReLU mask and leaves the
   per-channel partial sums, so the BatchNorm backward is one final sum and one pass over
-  the pixels instead of two passes (13 of the 20 BatchNorm layers;
+  the pixels instead of two passes; below a downsampling block the scatter of the 1x1
+  shortcut's data gradient does the same (16 of the 20 BatchNorm layers together;
   ``NANOFED_RESNET_FUSE_BN_BWD=0`` keeps the separate passes);
 * the head (global average pooling, classifier, cross-entropy, their gradients, the
   loss / accuracy accumulators) is two launches;
@@ -146,6 +147,8 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         self._fuse_bn_bwd = os.environ.get("NANOFED_RESNET_FUSE_BN_BWD", "1") != "0"
         # recompute the ReLU mask of a BatchNorm without residual from its input (else read it)
         self._remask = os.environ.get("NANOFED_RESNET_REMASK", "1") != "0"
+        # below a downsampling block: join the branches in the shortcut's scatter
+        self._join = os.environ.get("NANOFED_RESNET_JOIN", "1") != "0"
 
     # -- network plan ---------------------------------------------------------------------
     def _plan(self, model: ResNet18) -> tuple[_Unit, list[_Block]]:
@@ -228,6 +231,10 @@ class ResNetNativeTrainer(TorchGroupTrainer):
                         raise DeviceError("data gradients need channel counts that are multiples of 8")
                     d["dcol"] = bf(N * ho * ho, u.kp)
                     d["dx"] = bf(N, u.hin, u.hin, u.cin)
+                    # rows of partial sums per group when the scatter joins the branches
+                    d["jblocks"] = (go.col2im_join_blocks(B, u.hin, u.hin, u.cin)
+                                    if 256 % (u.cin // 8) == 0 else 0)
+                    ws_pre = max(ws_pre, Gn * d["jblocks"] * 2 * u.cin)
                     slabs = max(slabs, go.gemm_slab_floats(M, u.kp, C, gemm_ops.NN, Gn))
             bufs["units"][u.conv] = d
         for blk in self._blocks:
@@ -343,8 +350,13 @@ class ResNetNativeTrainer(TorchGroupTrainer):
         go.gemm_batched(gemm_ops.NN, d["dyp"], w, d["dcol"], rows,
                         u.kp, C, C, u.kp, u.kp, Gn, rows * C, w.stride, rows * u.kp, bufs["slabs"],
                         stream)
-        go.col2im(d["dcol"], d["dx"], N, u.hin, u.hin, u.cin, u.hout, u.hout, u.k, u.stride, u.pad,
-                  u.kp)
+        if consumer is not None:
+            cd = bufs["units"][consumer.conv]
+            go.col2im_join(d["dcol"], d["dx"], add, cd["out"], cd["y"], bufs["ws_pre"], Gn, B,
+                           u.hin, u.hin, u.cin, u.hout, u.hout, u.k, u.stride, u.pad, u.kp)
+        else:
+            go.col2im(d["dcol"], d["dx"], N, u.hin, u.hin, u.cin, u.hout, u.hout, u.k, u.stride,
+                      u.pad, u.kp)
         return d["dx"]
 
     # -- one optimisation step of clients g0 .. g0 + Gn - 1 ----------------------------------
@@ -398,8 +410,11 @@ class ResNetNativeTrainer(TorchGroupTrainer):
             if joins:
                 da, db, pre = dxa, None, units[blk.u1.conv]["dtiles"]
             elif blk.us is not None:
-                dxb = self._unit_bwd(blk.us, x_in, gout, None, None, False, g0, Gn, bufs)
-                da, db, pre = dxa, dxb, 0
+                # the shortcut's scatter adds the main branch, masks and leaves the sums
+                jb = units[blk.us.conv]["jblocks"] if fuse and self._join else 0
+                dxb = self._unit_bwd(blk.us, x_in, gout, None, None, False, g0, Gn, bufs,
+                                     consumer=below if jb else None, add=dxa if jb else None)
+                da, db, pre = (dxb, None, jb) if jb else (dxa, dxb, 0)
             else:
                 da, db, pre = dxa, gout, 0
         self._unit_bwd(self._stem, None, da, db, None, True, g0, Gn, bufs, pre=pre)

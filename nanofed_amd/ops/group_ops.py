@@ -40,6 +40,8 @@ _SIGS = {
     "nf_gemm_bf16_batched": ([I, I, P, P, P, P, P, P, I, I, I, L, L, L, I, I, L, L, L, L, P], I),
     "nf_im2col": ([P, P, I, I, I, I, I, I, I, I, I, I, I, P], I),
     "nf_col2im": ([P, P, I, I, I, I, I, I, I, I, I, I, I, P], I),
+    "nf_col2im_join_blocks": ([I, I, I, I], I),
+    "nf_col2im_join_g": ([P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P], I),
     "nf_stem_patches": ([P, P, P, I, I, I, P, P, P], I),
     "nf_pool_fc_ce": ([P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, I, P], I),
     "nf_fc_grads": ([P, P, P, P, P, P, P, I, I, I, I, L, P], I),
@@ -483,6 +485,42 @@ def col2im(col: torch.Tensor, dx: torch.Tensor, n: int, h: int, w: int, c: int, 
     library.check(
         _fn("nf_col2im")(_p(col), _p(dx), n, h, w, c, ho, wo, k, k, stride, pad, kp, _stream(col)),
         "col2im",
+    )
+
+
+def col2im_join_blocks(b: int, h: int, w: int, c: int) -> int:
+    """Rows of partial sums ``col2im_join`` writes per group."""
+    return int(_fn("nf_col2im_join_blocks")(b, h, w, c))
+
+
+def col2im_join(col: torch.Tensor, dx: torch.Tensor, add: torch.Tensor | None, mask: torch.Tensor,
+                xpre: torch.Tensor, partial: torch.Tensor, G: int, b: int, h: int, w: int, c: int,
+                ho: int, wo: int, k: int, stride: int, pad: int, kp: int) -> None:
+    """``col2im`` for G groups of ``b`` images that also finishes the gradient for the
+    BatchNorm whose ReLU output the convolution read: ``dx = (col2im + add)`` where
+    ``mask > 0``, else 0, and ``partial`` ``[G, col2im_join_blocks, 2, c]`` receives the sums of
+    dx and dx * xpre that ``bn_bwd_pre`` takes."""
+    _positive(G=G, b=b, h=h, w=w, c=c, ho=ho, wo=wo, k=k, stride=stride, kp=kp)
+    if kp < k * k * c or kp % 8 or pad < 0:
+        raise DeviceError(f"col2im_join: padded patch length {kp} for {k}x{k}x{c}")
+    if (h + 2 * pad - k) // stride + 1 != ho or (w + 2 * pad - k) // stride + 1 != wo:
+        raise DeviceError("col2im_join: output size does not follow from input, kernel, stride, pad")
+    if c % 8 or 256 % (c // 8):
+        raise DeviceError(f"col2im_join: {c} channels (c / 8 must divide 256)")
+    n_in = G * b * h * w * c
+    _need(col, "col2im_join patch matrix", BF16, G * b * ho * wo * kp)
+    _need(dx, "col2im_join dx", BF16, n_in)
+    _need(add, "col2im_join add", BF16, n_in, optional=True)
+    _need(mask, "col2im_join mask", BF16, n_in)
+    _need(xpre, "col2im_join xpre", BF16, n_in)
+    _need(partial, "col2im_join partial sums", F32, G * col2im_join_blocks(b, h, w, c) * 2 * c)
+    for t, what in ((add, "add"), (mask, "mask"), (xpre, "xpre")):
+        if t is not None and t.data_ptr() == dx.data_ptr():
+            raise DeviceError(f"col2im_join: dx must not alias {what}")
+    library.check(
+        _fn("nf_col2im_join_g")(_p(col), _p(dx), _p(add), _p(mask), _p(xpre), _p(partial), G, b, h,
+                                w, c, ho, wo, k, k, stride, pad, kp, _stream(col)),
+        "col2im_join_g",
     )
 
 

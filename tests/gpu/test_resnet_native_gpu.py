@@ -210,6 +210,54 @@ def test_data_gradient_with_the_batchnorm_backward_epilogue(G, B, H, cin, cout, 
         assert _rel(gb[g, C : 2 * C], be.grad) < 1e-2
 
 
+@pytest.mark.parametrize("G,B,H,C,k,two", [(3, 8, 32, 64, 1, True), (2, 8, 16, 128, 3, True),
+                                           (2, 16, 8, 256, 1, False)])
+def test_scatter_with_the_batchnorm_backward_join(G, B, H, C, k, two):
+    """col2im_join + bn_bwd_pre against col2im followed by bn_bwd (second branch, ReLU mask,
+    d(residual)): the joined gradient has the same bits, the BatchNorm results agree."""
+    torch.manual_seed(G + H + C + k)
+    N, Ho, pad, rows = G * B, H // 2, k // 2, B * H * H
+    kp = k * k * C
+    col = torch.randn(N * Ho * Ho, kp, device=DEV).to(BF)
+    prow = 2 * C + 64
+    params = torch.zeros(G, prow, device=DEV)
+    params[:, :C] = torch.rand(G, C, device=DEV) + 0.5
+    params[:, C : 2 * C] = torch.randn(G, C, device=DEV) * 0.1
+    gamma, beta = Ref(params, 0), Ref(params, C)
+    x = (torch.randn(N, H, H, C, device=DEV) * 2 + 0.3).to(BF)
+    res = torch.randn_like(x)
+    y = torch.empty_like(x)
+    stats = torch.empty(G, 2, C, device=DEV)
+    ws = torch.empty(go.bn_workspace_floats(G, C), device=DEV)
+    go.bn_fwd(x, res, y, gamma, beta, None, None, stats, ws, G, rows, C, True, 0.1, 1e-5)
+    other = torch.randn_like(x) if two else None
+
+    plain = torch.empty_like(x)
+    go.col2im(col, plain, N, H, H, C, Ho, Ho, k, 2, pad, kp)
+    dxa, dres = torch.empty_like(x), torch.empty_like(x)
+    ga = torch.zeros(G, prow, device=DEV, dtype=BF)
+    go.bn_bwd(plain, other, y, x, stats, gamma, dxa, dres, Ref(ga, 0), Ref(ga, C), ws, G, rows, C,
+              True)
+
+    nb = go.col2im_join_blocks(B, H, H, C)
+    pre = torch.full((G * nb, 2, C), float("nan"), device=DEV)
+    gz = torch.empty_like(x)
+    go.col2im_join(col, gz, other, y, x, pre, G, B, H, H, C, Ho, Ho, k, 2, pad, kp)
+    dxb = torch.empty_like(x)
+    gb = torch.zeros(G, prow, device=DEV, dtype=BF)
+    go.bn_bwd_pre(gz, x, stats, gamma, dxb, Ref(gb, 0), Ref(gb, C), pre, nb, ws, G, rows, C)
+    assert torch.equal(gz, dres)
+    assert torch.isfinite(pre).all()
+    for g in range(G):
+        gf = gz[g * B : (g + 1) * B].float().view(-1, C)
+        xf = x[g * B : (g + 1) * B].float().view(-1, C)
+        sums = pre[g * nb : (g + 1) * nb].sum(0)
+        torch.testing.assert_close(sums[0], gf.sum(0), rtol=2e-3, atol=0.5)
+        torch.testing.assert_close(sums[1], (gf * xf).sum(0), rtol=2e-3, atol=0.5)
+    assert _rel(dxb, dxa) < 1e-2
+    assert _rel(gb[:, : 2 * C], ga[:, : 2 * C]) < 1e-2
+
+
 def test_fused_batchnorm_backward_trains_the_same_models(monkeypatch):
     """The trainer with the BatchNorm backward folded into the data gradients against the
     trainer with the separate passes: same gradients up to the order in which the
