@@ -73,6 +73,51 @@ def test_batchnorm_operands():
                   G, rows, C, True)
 
 
+def test_fused_batchnorm_backward_operands():
+    """The data gradient / scatter with the BatchNorm backward epilogue, and the BatchNorm
+    pass that takes their partial sums."""
+    G, B, H, W, ci, co = 2, 64, 32, 32, 64, 64
+    n = G * B * H * W
+    dy, dx, act = z(n * co), z(n * ci), z(n * ci)
+    w = Ref(z(G, 9 * ci * co), 0)
+    arena = z(G, 4 * ci, dtype=F32)
+    stats = z(G * 2 * ci, dtype=F32)
+    # (what a real caller sizes with conv3x3_tiles; here any count that is clearly too small)
+    small = z(8, dtype=F32)
+    with pytest.raises(DeviceError, match="colsum"):
+        go.conv3x3_dgrad(dy, w, dx, G, B, H, W, ci, co, fuse=go.BnBwdFuse(act, act, None, small))
+    big = z(G * 1024 * 2 * ci, dtype=F32)
+    with pytest.raises(DeviceError, match="xpre"):
+        go.conv3x3_dgrad(dy, w, dx, G, B, H, W, ci, co, fuse=go.BnBwdFuse(act, act[:-8].clone(), None, big))
+    with pytest.raises(DeviceError, match="alias"):
+        go.conv3x3_dgrad(dy, w, dx, G, B, H, W, ci, co, fuse=go.BnBwdFuse(act, act, dx, big))
+    with pytest.raises(DeviceError, match="stats"):   # no mask: the statistics are needed
+        go.conv3x3_dgrad(dy, w, dx, G, B, H, W, ci, co, fuse=go.BnBwdFuse(None, act, None, big))
+    with pytest.raises(DeviceError, match="beta"):
+        go.conv3x3_dgrad(dy, w, dx, G, B, H, W, ci, co,
+                         fuse=go.BnBwdFuse(None, act, None, big, stats, Ref(arena, 0), Ref(arena, 4 * ci - 8)))
+    rows = B * H * W
+    ws = z(go.bn_workspace_floats(G, ci), dtype=F32)
+    gb = z(G, 4 * ci)
+    with pytest.raises(DeviceError, match="partial sums"):
+        go.bn_bwd_pre(act, act, stats, Ref(arena, 0), dx, Ref(gb, 0), Ref(gb, ci), small, 256, ws, G,
+                      rows, ci)
+    with pytest.raises(DeviceError, match="pre_blocks"):
+        go.bn_bwd_pre(act, act, stats, Ref(arena, 0), dx, Ref(gb, 0), Ref(gb, ci), big, 0, ws, G,
+                      rows, ci)
+    # scatter of a 1x1 / stride 2 convolution, 16x16 -> 8x8 per image
+    Bs, Hs, C = 8, 16, 64
+    col = z(G * Bs * 8 * 8 * C)
+    t = z(G * Bs * Hs * Hs * C)
+    with pytest.raises(DeviceError, match="mask"):
+        go.col2im_join(col, t.clone(), None, t[:-8].clone(), t, big, G, Bs, Hs, Hs, C, 8, 8, 1, 2, 0, C)
+    with pytest.raises(DeviceError, match="must divide 256"):
+        go.col2im_join(z(G * Bs * 8 * 8 * 48), z(G * Bs * Hs * Hs * 48), None, z(G * Bs * Hs * Hs * 48),
+                       z(G * Bs * Hs * Hs * 48), big, G, Bs, Hs, Hs, 48, 8, 8, 1, 2, 0, 48)
+    with pytest.raises(DeviceError, match="alias"):
+        go.col2im_join(col, t, t, t.clone(), t.clone(), big, G, Bs, Hs, Hs, C, 8, 8, 1, 2, 0, C)
+
+
 def test_batched_gemm_operands():
     G, M, N, K = 2, 128, 64, 72
     a, b, c = z(G, M * K), z(G, N * K), z(G, M * N)
