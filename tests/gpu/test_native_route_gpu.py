@@ -68,19 +68,23 @@ def test_native_and_pytorch_paths_learn_the_same_task(monkeypatch):
     def run(native_on):
         monkeypatch.setenv("NANOFED_NATIVE_TRAINER", "1" if native_on else "0")
         loader, _, _ = _loader(2048)
-        trainer = TorchTrainer(TC(epochs=3, batch_size=64, learning_rate=0.05, device="cuda"))
+        trainer = TorchTrainer(TC(epochs=6, batch_size=64, learning_rate=0.05, device="cuda"))
         torch.manual_seed(1)
         model = MNISTModel().to("cuda")
         opt = torch.optim.SGD(model.parameters(), lr=0.05)
-        out = [trainer.train_epoch(model, loader, opt, e) for e in range(3)]
+        out = [trainer.train_epoch(model, loader, opt, e) for e in range(6)]
         assert ("_native_sessions" in trainer.__dict__) == native_on
         return out
 
     a, b = run(True), run(False)
-    # different shuffles and dropout streams, bf16 against fp32: the curves agree
-    # in the large, not in the digits
-    assert a[-1].loss == pytest.approx(b[-1].loss, rel=0.25, abs=0.1)
-    assert a[-1].accuracy == pytest.approx(b[-1].accuracy, abs=0.08)
+    # Different shuffles and dropout streams, bf16 against fp32: the curves agree in the
+    # large, not in the digits.  Compared where both have flattened (the loss falls from
+    # 1.5 to 0.3 within two epochs, and which epoch that is depends on the shuffle:
+    # tools/probes/route_curve_probe.py prints the curves of three seeds).
+    assert a[0].loss > 1.5 and b[0].loss > 1.5
+    assert a[-1].loss < 0.25 and b[-1].loss < 0.25
+    assert a[-1].loss == pytest.approx(b[-1].loss, abs=0.08)
+    assert a[-1].accuracy == pytest.approx(b[-1].accuracy, abs=0.04)
 
 
 def test_one_epoch_equals_one_engine_round_of_one_client():
