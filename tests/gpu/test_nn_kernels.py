@@ -84,7 +84,8 @@ def test_gelu_colsum_sgd():
     assert torch.equal(sh.cpu(), pd.cpu().to(BF))
 
 
-@pytest.mark.parametrize("R,V", [(512, 50257), (33, 1000), (8, 8)])
+# GPT-2 vocabulary, small rows, one row piece, long rows
+@pytest.mark.parametrize("R,V", [(512, 50257), (33, 1000), (8, 8), (16, 20000), (4, 60000)])
 def test_cross_entropy(R, V):
     ld = (V + 63) // 64 * 64
     logits = torch.full((R, ld), 50.0, dtype=BF)
