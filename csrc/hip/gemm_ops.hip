@@ -122,10 +122,17 @@ __device__ __forceinline__ bf16x8 km_frag(const char* tile, int k0, int x0, int 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__device__ __forceinline__ void dma16(const bf16* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// One LDS-DMA piece as a buffer load: the tile's first element of the K step is the
+// (wave-uniform) base of the descriptor, the lane's place in the tile a 32-bit byte offset
+// that does not change over the K loop, the LDS address a scalar - so a piece costs its
+// wave s_mov m0 + buffer_load ... lds and no vector instruction (as a global load with a
+// 64-bit address per lane it was five VALU instructions and a v_readfirstlane for M0).
+__device__ __forceinline__ void dma16(const bf16* step_base, unsigned lane_bytes, char* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(step_base), 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+        static_cast<int>(lane_bytes), 0, 0, 0);
 }
 
 template <int N>
@@ -163,7 +170,8 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     constexpr int BM = G::BM, BN = G::BN, RM = G::RM, RN = G::RN, PA = G::PA, PB = G::PB;
     constexpr int STAGES = G::STAGES, D = STAGES - 1;  // K steps in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS bases stay scalar
     const int wm = wave / G::WN, wn = wave % G::WN;
     const int n = lane & 31, h = lane >> 5;
     int tm, tn;
@@ -301,8 +309,12 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     };
     // one DMA piece of the K step (A pieces first, then B pieces)
     auto issue_piece = [&](int kt, int stage, int p) {
-        if (p < PA) dma16(g.A + (srca[p] + kt * stepa), dsta + stage * G::STAGE + p * 1024);
-        else dma16(g.B + (srcb[p - PA] + kt * stepb), dstb + stage * G::STAGE + (p - PA) * 1024);
+        if (p < PA)
+            dma16(g.A + static_cast<long>(kt) * stepa, static_cast<unsigned>(srca[p]) * 2u,
+                  dsta + stage * G::STAGE + p * 1024);
+        else
+            dma16(g.B + static_cast<long>(kt) * stepb, static_cast<unsigned>(srcb[p - PA]) * 2u,
+                  dstb + stage * G::STAGE + (p - PA) * 1024);
     };
     auto issue_all = [&](int kt, int stage) {
 #pragma unroll

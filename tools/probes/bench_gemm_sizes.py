@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nanofed_amd.ops import gemm_ops
 from tools.bench_gemm import timed
 torch.cuda.set_device(0)
