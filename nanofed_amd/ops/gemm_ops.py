@@ -112,6 +112,15 @@ def choose_geometry(M: int, N: int, K: int = 0, layout: int = 0, batch: int = 1)
             return GEO_256
     if layout == TN and t256 >= 224 and ksteps >= 32 and max(M, N) >= 16384 and min(M, N) >= 512:
         return GEO_256        # the LM head's weight gradient: one very long side (377 vs 408 us)
+    if layout == NN and t256 >= 256 and ksteps >= 48 and min(M, N) >= 512:
+        # data gradients of a group of clients with a long reduction (8 x 4096 x 768, K = 3072:
+        # 177 against 188 us; at K = 2304 the small tile is still ahead, 128 against 133 us)
+        return GEO_256
+    if layout == TN and batch > 1 and t256 >= 256 and ksteps >= 32 and 512 <= M < N:
+        # weight gradients of a group whose 256 x 256 tiles would leave a round mostly empty,
+        # with the short side first (8 x 768 x 3072: 232 against 250 us; 8 x 3072 x 768 stays
+        # on the small tile, 219 against 224 us)
+        return GEO_256x128
     if t256 >= 1024 and layout == NT and not fits192:
         return GEO_256x128    # very wide outputs with a short K loop (the LM head)
     if layout == NT and N % 192 == 0:

@@ -64,3 +64,10 @@ def test_batched_gemm_heuristics_count_the_tiles_of_all_problems():
     # 6.0 rounds of 256 x 256 tiles: the big tile; 4.5 rounds (above): 128 x 192
     assert gemm_ops.choose_geometry(4096, 3072, 768, gemm_ops.NT, batch=8) == gemm_ops.GEO_256
     assert gemm_ops.choose_geometry(4096, 3072, 768, gemm_ops.NN, batch=8) == gemm_ops.GEO_256
+    # a group's data gradient with a long reduction takes the big tile, a shorter one not
+    assert gemm_ops.choose_geometry(4096, 768, 3072, gemm_ops.NN, batch=8) == gemm_ops.GEO_256
+    assert gemm_ops.choose_geometry(4096, 768, 2304, gemm_ops.NN, batch=8) == gemm_ops.GEO_128_2
+    assert gemm_ops.choose_geometry(4096, 768, 3072, gemm_ops.NN) == gemm_ops.GEO_128_2
+    # a group's weight gradient: short side first -> 256 x 128, long side first -> 128 x 128
+    assert gemm_ops.choose_geometry(768, 3072, 4096, gemm_ops.TN, batch=8) == gemm_ops.GEO_256x128
+    assert gemm_ops.choose_geometry(3072, 768, 4096, gemm_ops.TN, batch=8) == gemm_ops.GEO_128_2
