@@ -3,6 +3,7 @@
 
     python scripts/changelog.py 0.2.0            # since the latest tag
     python scripts/changelog.py 0.2.0 --since v0.1.0 --dry-run
+    python scripts/changelog.py 0.2.0 --replace  # again, after more commits
 
 Reads ``git log`` since the latest tag (or ``--since``), sorts the subjects by their
 conventional-commit type (``feat(scope): subject``) and writes
@@ -131,11 +132,21 @@ def render_rst(buckets: dict[str, list[Commit]], url: str) -> str:
     return "\n".join(items)
 
 
-def merge_markdown(existing: str | None, section: str, version: str) -> str | None:
-    """The changelog with ``section`` on top, or None when ``version`` is in it."""
+def drop_section(existing: str, version: str) -> str:
+    """``existing`` without the section of ``version`` (up to the next ``## [`` heading)."""
+    v = re.escape(version.lstrip("v"))
+    return re.sub(rf"^## \[{v}\].*?(?=^## \[|\Z)", "", existing, flags=re.M | re.S)
+
+
+def merge_markdown(existing: str | None, section: str, version: str,
+                   replace: bool = False) -> str | None:
+    """The changelog with ``section`` on top, or None when ``version`` is in it (with
+    ``replace`` its old section is dropped first: a release that is still being worked on)."""
     v = version.lstrip("v")
     if existing and re.search(rf"^## \[{re.escape(v)}\]", existing, flags=re.M):
-        return None
+        if not replace:
+            return None
+        existing = drop_section(existing, version)
     body = (existing or "").strip()
     if body.startswith(HEADER):
         body = body[len(HEADER):].lstrip()
@@ -153,6 +164,8 @@ def main(argv: list[str] | None = None) -> int:
     ap.add_argument("--path", default=".", help="repository root (default: current directory)")
     ap.add_argument("--since", help="tag or commit to start after (default: the latest tag)")
     ap.add_argument("--dry-run", action="store_true", help="print, write nothing")
+    ap.add_argument("--replace", action="store_true",
+                    help="rewrite the version's section when CHANGELOG.md already has one")
     args = ap.parse_args(argv)
     try:
         repo = Repo(args.path)
@@ -172,7 +185,8 @@ def main(argv: list[str] | None = None) -> int:
         print(render_rst(buckets, url))
         return 0
     changelog = repo.root / "CHANGELOG.md"
-    merged = merge_markdown(changelog.read_text() if changelog.exists() else None, section, args.version)
+    merged = merge_markdown(changelog.read_text() if changelog.exists() else None, section, args.version,
+                            replace=args.replace)
     if merged is None:
         print(f"CHANGELOG.md already has a section for {args.version}")
     else:

@@ -80,6 +80,21 @@ def test_changelog_and_release_notes_are_written_once(repo, capsys):
     assert "does not exist" in capsys.readouterr().out  # no v0.3.0.rst page yet
 
 
+def test_replace_rewrites_the_section_of_a_release_in_progress():
+    old = (f"{changelog.HEADER}\n\n## [0.2.0] - 2026-01-01\n\n- first list\n\n"
+           "## [0.1.0] - 2025-01-01\n\n- older\n")
+    new_section = "## [0.2.0] - 2026-02-02\n\n- second list\n"
+    assert changelog.merge_markdown(old, new_section, "0.2.0") is None
+    out = changelog.merge_markdown(old, new_section, "v0.2.0", replace=True)
+    assert out.count("## [0.2.0]") == 1 and "second list" in out and "first list" not in out
+    assert "## [0.1.0] - 2025-01-01" in out and "- older" in out
+    assert out.index("## [0.2.0]") < out.index("## [0.1.0]")
+    # the last section of the file can be the one that is replaced
+    only = f"{changelog.HEADER}\n\n## [0.2.0] - 2026-01-01\n\n- first list\n"
+    out = changelog.merge_markdown(only, new_section, "0.2.0", replace=True)
+    assert "first list" not in out and "second list" in out
+
+
 def test_only_commits_after_the_latest_tag_are_listed(repo):
     _git(repo, "tag", "v0.1.0")
     (repo / "new").write_text("x")
