@@ -230,8 +230,10 @@ class NativeBuffers:
             split, wpc, conv1_split = 3, 64, 2
         elif parent is not None:
             # pairs of clients on concurrent streams (measured for 8 clients: 36.5
-            # rounds/s against 34.1 with the two-client row above)
-            split, wpc, conv1_split = 1, 64, 1
+            # rounds/s against 34.1 with the two-client row above; 48 weight-gradient
+            # workgroups per client against 64: 42.0-42.2 against 41.6-41.8 rounds/s, 32 the
+            # same, 96 and 24 slower - tools/probes/geometry_resweep.sh)
+            split, wpc, conv1_split = 1, 48, 1
         else:
             split, wpc, conv1_split = 1, CONV2_WG_PER_CLIENT, 1
         if cfg is not None and cfg.conv_split in (1, 3) and dp is None:
