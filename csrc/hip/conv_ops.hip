@@ -83,6 +83,7 @@ struct ConvGeo {
     int tpg;               // pixel tiles per group (of the launch's tile size)
     long wgs;              // weight elements between consecutive groups
     int rp, bp;            // forward kernel: bytes between patch rows / bands in LDS (padded)
+    int xorder;            // forward kernel: 1-D launch in weight-sharing order (see launch_fwd)
 };
 
 // Patch pixel pp of the tile whose first image row (index over b * H + y) is row0:
@@ -148,7 +149,17 @@ conv3x3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16*
     char* s_a = smem + kBRegion;      // [patch pixel][CH ic]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pw = wave % PXW, kw = KSW == 1 ? 0 : wave / PXW;
-    const int tile = blockIdx.x, oc0 = blockIdx.y * 64;
+    int tile = blockIdx.x, oc0 = blockIdx.y * 64;
+    if (g.xorder) {
+        // the workgroups of one XCD (ids congruent mod 8) take a contiguous run of
+        // (group, output-channel tile, pixel tile) triples, pixel tiles fastest: the pixel
+        // tiles that read the same weight slice follow each other on one L2
+        const int t = nfix::gemm_tile_index(blockIdx.x, gridDim.x);
+        const int blk = t / g.tpg, oct = g.Cout >> 6;
+        const int grp = blk / oct;
+        tile = grp * g.tpg + (t - blk * g.tpg);
+        oc0 = (blk - grp * oct) * 64;
+    }
     const int row0 = (tile * TP) >> g.logW;
     w += (tile / g.tpg) * g.wgs;  // this group's weights
 
@@ -660,6 +671,7 @@ bool make_geo(int B, int H, int W, int Cin, int Cout, int tp, int max_patch, Con
     g->Cin = Cin; g->Cout = Cout;
     g->tpg = static_cast<int>(M / tp);
     g->wgs = 0;
+    g->xorder = 0;
     g->rp = g->bp = 0;  // set by fwd_geo for the forward kernel
     return g->np <= max_patch;
 }
@@ -763,7 +775,23 @@ int launch_fwd(const void* x, const void* w, void* y, float* colsum, int B, int 
     if ((M / G) % tp != 0 || (w_stride & 7) != 0) return -3;
     g.tpg = static_cast<int>(M / G / tp);
     g.wgs = w_stride;
-    const dim3 grid(static_cast<unsigned>(M / tp), Cout / 64);
+    // Workgroup order.  Ids are dealt round-robin to the 8 XCDs (one L2 each).  With pixel
+    // tiles as the fast grid dimension the tiles that share a weight slice - the largest
+    // thing a workgroup reads: 1152 Cin bytes against 2.6 TP Cin for its patch - land on 8
+    // different L2s and the slice is fetched 8 times (the 512-channel stage fetched 227 MB
+    // from HBM per launch for 38 MB of weights and 8 MB of activations).  The other order
+    // keeps a slice on one L2 and fetches each patch once per output-channel tile instead;
+    // taken when that is less traffic by this estimate.  NANOFED_CONV_XORDER=0|1 pins it.
+    {
+        const char* e = getenv("NANOFED_CONV_XORDER");  // (read per launch: tests switch it)
+        const int pinned = e == nullptr ? -1 : (e[0] != '0' ? 1 : 0);
+        const double wbytes = 2.0 * G * Cout * 9.0 * Cin, abytes = 2.0 * M * Cin;
+        const int oct = Cout / 64, share = g.tpg < 8 ? g.tpg : 8;
+        const bool better = wbytes + abytes * oct < wbytes * share + abytes;
+        g.xorder = pinned >= 0 ? pinned : (better ? 1 : 0);
+    }
+    const dim3 grid = g.xorder ? dim3(static_cast<unsigned>(M / tp) * (Cout / 64))
+                               : dim3(static_cast<unsigned>(M / tp), Cout / 64);
     const bf16* xp = static_cast<const bf16*>(x);
     const bf16* wp = static_cast<const bf16*>(w);
     bf16* yp = static_cast<bf16*>(y);

@@ -32,8 +32,12 @@ STAGES = [(2, 8, 32, 64, 64), (3, 8, 16, 128, 128), (2, 16, 8, 256, 256), (2, 32
           (2, 8, 16, 64, 128)]
 
 
+@pytest.mark.parametrize("xorder", ["0", "1"])
 @pytest.mark.parametrize("G,B,H,cin,cout", STAGES)
-def test_grouped_conv3x3_against_the_library_per_group(G, B, H, cin, cout):
+def test_grouped_conv3x3_against_the_library_per_group(G, B, H, cin, cout, xorder, monkeypatch):
+    # both workgroup orders of the forward / data-gradient launch (pixel tiles fastest, or
+    # the tiles that share a weight slice kept on one XCD)
+    monkeypatch.setenv("NANOFED_CONV_XORDER", xorder)
     torch.manual_seed(G * 1000 + H)
     assert go.conv3x3_supported(G, B, H, H, cin, cout)
     row = cout * 9 * cin + 64  # rows of a pretend arena: a gap after the tensor
