@@ -1344,25 +1344,139 @@ __global__ void __launch_bounds__(384) conv2_wgrad_kernel(MnistCtx c) {
     conv2_wgrad_body(c, blockIdx.x, blockIdx.y);
 }
 
+// The same for a workgroup of four waves (the triple launch below: with 256-thread
+// workgroups two of them share a CU, with 384-thread ones only one fits).  Waves: output
+// channel half x tap group, taps 0-4 and 5-8; every tap's accumulator adds the same products
+// in the same order as in the six-wave body, so the results have the same bits.  Staging: the
+// 384 pooled-gradient items of a band are items tid and tid + 256, the 1040 pieces of the
+// conv1 activation band pieces tid + 256 i.
+__device__ __forceinline__ void conv2_wgrad_body4(const MnistCtx& c, int wg, int g) {
+    if (client_idle(c, g)) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_da = smem;               // [192 px][64 oc], pitch 192
+    char* s_a1 = smem + kWgDaBytes;  // [260 px][32 c], pitch 64
+    char* lut = s_a1 + kWgA1Bytes;   // pooling-window masks (PoolWindow)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ocb = wave & 1, tg = wave >> 1;
+    const int tap0 = tg * 5, ntap = tg == 0 ? 5 : 4;
+    const int nit = 3 * c.B / c.WPC;  // image-bands per workgroup
+    const int it0 = wg * nit;
+    f32x16 acc[5] = {{0}, {0}, {0}, {0}, {0}};
+    const int li = lane & 15;
+    const int lq = li >> 2;
+    const int lcol = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    // byte offset of tap (kh, kw) in the activation band: (kh * 26 + kw) pixels
+    int toff[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int t9 = min(tap0 + t, 8);
+        toff[t] = ((t9 / 3) * 26 + t9 % 3) * 64;
+    }
+
+    const bool item2 = tid < 128;  // items tid + 256 exist for the first 128 threads
+    const int i2 = item2 ? tid + 256 : tid;
+    auto da_of = [&](int item) {
+        const int wpi = item >> 3, wprow = wpi / 12, wpcol = wpi - wprow * 12;
+        return s_da + (2 * wprow * 24 + 2 * wpcol) * kWgDaPitch + (item & 7) * 16;
+    };
+    char* const da_dst0 = da_of(tid);
+    char* const da_dst1 = da_of(i2);
+    const bool has4 = tid + 1024 < 1040;
+    const int q4 = min(tid + 1024, 1039);
+    uint4 pv0, pv1, pa0, pa1, pa2, pa3, pa4;
+    uint2 pm0, pm1;
+#define NF_WG4_ISSUE(it_)                                                               \
+    {                                                                                   \
+        const int gi_ = it0 + (it_);                                                    \
+        const int im_ = gi_ / 3, band_ = gi_ - im_ * 3;                                 \
+        const long img_ = static_cast<long>(g) * c.B + im_;                             \
+        const long off_ = (img_ * kP2Pix + band_ * 48) * kC2;                           \
+        pv0 = *reinterpret_cast<const uint4*>(c.dp2 + off_ + tid * 8);                  \
+        pm0 = *reinterpret_cast<const uint2*>(c.pmask + off_ + tid * 8);                \
+        pv1 = *reinterpret_cast<const uint4*>(c.dp2 + off_ + i2 * 8);                   \
+        pm1 = *reinterpret_cast<const uint2*>(c.pmask + off_ + i2 * 8);                 \
+        const uint4* sa1_ = reinterpret_cast<const uint4*>(                             \
+            c.a1 + (img_ * kA1Pix + band_ * 8 * 26) * kA1C);                            \
+        pa0 = sa1_[tid]; pa1 = sa1_[tid + 256]; pa2 = sa1_[tid + 512];                  \
+        pa3 = sa1_[tid + 768]; pa4 = sa1_[q4];                                          \
+    }
+    NF_WG4_ISSUE(0)
+    pool_lut_init(lut, tid);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();
+        {
+            const PoolWindow win(pv0, pm0, lut);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(da_dst0 + ((q >> 1) * 24 + (q & 1)) * kWgDaPitch) = win.at(q);
+        }
+        if (item2) {
+            const PoolWindow win(pv1, pm1, lut);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(da_dst1 + ((q >> 1) * 24 + (q & 1)) * kWgDaPitch) = win.at(q);
+        }
+        *reinterpret_cast<uint4*>(s_a1 + tid * 16) = pa0;
+        *reinterpret_cast<uint4*>(s_a1 + (tid + 256) * 16) = pa1;
+        *reinterpret_cast<uint4*>(s_a1 + (tid + 512) * 16) = pa2;
+        *reinterpret_cast<uint4*>(s_a1 + (tid + 768) * 16) = pa3;
+        if (has4) *reinterpret_cast<uint4*>(s_a1 + q4 * 16) = pa4;
+        if (it + 1 < nit) NF_WG4_ISSUE(it + 1)
+        __syncthreads();
+#undef NF_WG4_ISSUE
+#pragma unroll 2
+        for (int ks = 0; ks < 12; ++ks) {
+            const bf16x8 Afr = load_tr_frag(s_da, kWgDaPitch, ks * 16, ocb * 32, lane);
+            const int gi0 = 4 * ks + 2 * h;
+            const int oy0 = gi0 / 6, ox0 = 4 * (gi0 - oy0 * 6);
+            const int gi1 = gi0 + 1;
+            const int oy1 = gi1 / 6, ox1 = 4 * (gi1 - oy1 * 6);
+            const char* b0 = s_a1 + (oy0 * 26 + ox0 + lq) * 64 + lcol;
+            const char* b1 = s_a1 + (oy1 * 26 + ox1 + lq) * 64 + lcol;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (t < ntap) {
+                    const bf16x4 lo = lds_tr4(b0 + toff[t]);
+                    const bf16x4 hi = lds_tr4(b1 + toff[t]);
+                    const bf16x8 Bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = mfma32(Afr, Bfr, acc[t]);
+                }
+            }
+        }
+    }
+    float* part = c.conv2_part + (static_cast<long>(g) * c.WPC + wg) * kConv2Part;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        if (t < ntap) {
+            const int tap = tap0 + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = ocb * 32 + acc_row(r, lane);
+                part[(oc * 9 + tap) * 32 + n] = acc[t][r];
+            }
+        }
+    }
+}
+
 // conv2_dgrad, fc1_wgrad and conv2_wgrad in one launch: all three only need what
-// fc1_dgrad left behind.  conv2_wgrad is written for six waves, the other two for
-// four: their workgroups retire the two spare waves at once (a wave that has ended is
-// not waited for at barriers and holds no registers).  Workgroup indices: n_dg of
-// conv2_dgrad, then n_fw of fc1_wgrad, then conv2_wgrad's.
+// fc1_dgrad left behind.  Four-wave workgroups throughout (conv2_wgrad in its four-wave
+// form), so that two workgroups share a CU and the launch of one client - 192 + 72 + 192
+// workgroups - is resident at once (with the six-wave body the launch had 384-thread
+// workgroups, one per CU, and ran in two rounds).  The DP norm pass keeps the six-wave
+// kernel.  Workgroup indices: n_dg of conv2_dgrad, then n_fw of fc1_wgrad, then conv2_wgrad's.
 constexpr int kTripleLds = kPairLds > kWgLds ? kPairLds : kWgLds;
 
-__global__ void __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bwd_triple_kernel(MnistCtx c, int idx_off, int step, int n_dg, int n_fw) {
     const int bx = blockIdx.x;
-    if (bx < n_dg + n_fw) {
-        if (threadIdx.x >= 256) return;
-        if (bx < n_dg)
-            conv2_dgrad_body(c, idx_off, bx, blockIdx.y);
-        else
-            fc1_wgrad_body(c, step, bx - n_dg, blockIdx.y);
-    } else {
-        conv2_wgrad_body(c, bx - n_dg - n_fw, blockIdx.y);
-    }
+    if (bx < n_dg)
+        conv2_dgrad_body(c, idx_off, bx, blockIdx.y);
+    else if (bx < n_dg + n_fw)
+        fc1_wgrad_body(c, step, bx - n_dg, blockIdx.y);
+    else
+        conv2_wgrad_body4(c, bx - n_dg - n_fw, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -1713,7 +1827,7 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
             hipFuncAttributeMaxDynamicSharedMemorySize, kTripleLds);
         if (lds_ok != hipSuccess) return -20;
         const int n_dg = c->B * c->split;
-        hipLaunchKernelGGL(bwd_triple_kernel, dim3(n_dg + kFc1Tiles + c->WPC, c->G), dim3(384),
+        hipLaunchKernelGGL(bwd_triple_kernel, dim3(n_dg + kFc1Tiles + c->WPC, c->G), dim3(256),
                            kTripleLds, s, *c, idx_off, step, n_dg, kFc1Tiles);
         break;
     }

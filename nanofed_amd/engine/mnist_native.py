@@ -230,10 +230,11 @@ class NativeBuffers:
             split, wpc, conv1_split = 3, 64, 2
         elif parent is not None:
             # pairs of clients on concurrent streams (measured for 8 clients: 36.5
-            # rounds/s against 34.1 with the two-client row above; 48 weight-gradient
-            # workgroups per client against 64: 42.0-42.2 against 41.6-41.8 rounds/s, 32 the
-            # same, 96 and 24 slower - tools/probes/geometry_resweep.sh)
-            split, wpc, conv1_split = 1, 48, 1
+            # rounds/s against 34.1 with the two-client row above; weight-gradient
+            # workgroups per client, with the three backward kernels in one launch: 32 ->
+            # 45.2 rounds/s, 48 -> 45.0, 64 -> 44.7, 96 -> 42.0 -
+            # tools/probes/geometry_resweep.sh)
+            split, wpc, conv1_split = 1, 32, 1
         else:
             split, wpc, conv1_split = 1, CONV2_WG_PER_CLIENT, 1
         if cfg is not None and cfg.conv_split in (1, 3) and dp is None:
@@ -296,16 +297,15 @@ class NativeBuffers:
         # (micro-batches: the gradients are added up in the gradient arena first)
         c.fuse_sgd = 1 if (train and fuse_sgd and micro == 1) else 0
         c.micro = micro
-        # one client on the GPU: the three backward kernels that only need what fc1_dgrad
-        # left behind share one launch (69.0 -> 72.2 rounds/s at the time).  Two clients
-        # train as two concurrent chains, which fill the gaps of each other already: 74.0
-        # rounds/s with the pair launch against 71.5 with the triple (alternating runs on
-        # one box); neutral with four, -3 % with eight.
+        # The three backward kernels that only need what fc1_dgrad left behind share one
+        # launch of four-wave workgroups, two of which fit a CU (same bits as the separate
+        # launches).  Measured against the pair launch + conv2_wgrad, alternating runs on one
+        # box: 89.8 against 79.4 rounds/s with one client on the GPU, 82.4 / 71.6 with two,
+        # 62.8 / 58.1 with four, 44.9 / 42.1 with eight.  (With conv2_wgrad's six-wave body
+        # the launch had 384-thread workgroups, one per CU, and only paid for one client.)
         # NANOFED_MNIST_TRIPLE=0|1 overrides (measurements).
         triple = os.environ.get("NANOFED_MNIST_TRIPLE")
-        c.bwd_triple = int(triple == "1") if triple in ("0", "1") else int(total <= 1)
-        if invariant:
-            c.bwd_triple = 0
+        c.bwd_triple = int(triple == "1") if triple in ("0", "1") else 1
         c.ntotal = self.ntotal.data_ptr() if (train and (micro > 1 or cfg is not None
                                                and cfg.batch_size < BATCH)) else 0
         c.dp_normsq, c.dp_rowscale = self.dp_normsq.data_ptr(), self.dp_rowscale.data_ptr()

@@ -416,12 +416,13 @@ def test_client_groups_train_the_same_model(monkeypatch):
     assert outs[0][1] == outs[1][1]
 
 
-@pytest.mark.parametrize("clients", [1, 2])
+@pytest.mark.parametrize("clients", [1, 2, 8])
 def test_three_backward_kernels_in_one_launch_train_the_same_model(monkeypatch, clients):
-    """conv2_dgrad, fc1_wgrad and conv2_wgrad only need what fc1_dgrad left behind; with
-    one client on the GPU they share a launch (conv2_wgrad is written for six waves, the
-    others retire the two spare waves at once).  Same bodies, same order of additions:
-    the models agree bit for bit with the two-launch sequence."""
+    """conv2_dgrad, fc1_wgrad and conv2_wgrad only need what fc1_dgrad left behind and share
+    a launch of four-wave workgroups (conv2_wgrad in its four-wave form: taps 0-4 and 5-8
+    per wave pair instead of a kernel row per pair).  Every accumulator adds the same
+    products in the same order: the models agree bit for bit with the sequence of the pair
+    launch and the six-wave conv2_wgrad kernel."""
     from nanofed_amd.engine import EngineConfig, FederatedEngine
     from nanofed_amd.parallel import Communicator
 
@@ -438,10 +439,10 @@ def test_three_backward_kernels_in_one_launch_train_the_same_model(monkeypatch, 
         outs.append((eng.global_arena.data.clone(), [r.agg_metrics for r in reps]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
-    # the default: on with one client on the GPU, off otherwise
+    # the default: on, for any number of clients on the GPU
     monkeypatch.delenv("NANOFED_MNIST_TRIPLE")
     eng = FederatedEngine(cfg, comm=Communicator(device=torch.device("cuda", 0)))
-    assert eng.trainer.buf.ctx.bwd_triple == int(clients <= 1)
+    assert eng.trainer.buf.ctx.bwd_triple == 1
 
 
 def test_make_streams_returns_usable_streams():
