@@ -549,49 +549,45 @@ conv12_fwd_kernel(MnistCtx c, int idx_off) {
 // 64 different cache lines per instruction - made this kernel address-bound.)
 constexpr int kFc1KC = 288, kFc1S = kFc1K / kFc1KC;      // 32 slabs
 constexpr int kFc1Pitch = kFc1KC * 2 + 16;                // 592
-constexpr int kFc1FwdLds = (128 + 64) * kFc1Pitch;        // 113664
+// A workgroup computes 64 batch rows x 64 of the 128 hidden units of a slab (blockIdx.x =
+// 2 * slab + half): 76 KB of LDS instead of the 114 KB of a whole slab, so that a workgroup of
+// another chain's kernel fits on the CU beside it, and twice the workgroups (64 per client)
+// for a launch that does not fill the chip.  A wave owns one 32 x 32 tile; every output adds
+// the same products in the same order as before.
+constexpr int kFc1FwdLds = (64 + 64) * kFc1Pitch;         // 75776
 
 __global__ void __launch_bounds__(256) fc1_fwd_kernel(MnistCtx c) {
     if (client_idle(c, blockIdx.y)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;                     // [128 j][288 k]
-    char* s_a = smem + 128 * kFc1Pitch;   // [64 b][288 k]
-    const int kc = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    char* s_w = smem;                    // [64 j][288 k]
+    char* s_a = smem + 64 * kFc1Pitch;   // [64 b][288 k]
+    const int kc = blockIdx.x >> 1, nh = blockIdx.x & 1, g = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const bf16* wsrc = c.shadow + g * c.shadow_stride + c.off_f1w + kc * kFc1KC;
+    const int cb = wave & 1, rb = wave >> 1;  // column / row block of this wave's tile
+    const bf16* wsrc = c.shadow + g * c.shadow_stride + c.off_f1w +
+                       static_cast<long>(nh) * 64 * kFc1K + kc * kFc1KC;
     const bf16* asrc = c.p2 + static_cast<long>(g) * c.B * kFc1K + kc * kFc1KC;
     constexpr int kPiecesPerRow = kFc1KC / 8;  // 36
-#pragma unroll 6
-    for (int p = tid; p < 128 * kPiecesPerRow; p += 256) {
-        const int row = p / kPiecesPerRow, part = p - row * kPiecesPerRow;
-        *reinterpret_cast<uint4*>(s_w + row * kFc1Pitch + part * 16) =
-            *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * kFc1K + part * 8);
-    }
 #pragma unroll 3
     for (int p = tid; p < 64 * kPiecesPerRow; p += 256) {
         const int row = p / kPiecesPerRow, part = p - row * kPiecesPerRow;
+        *reinterpret_cast<uint4*>(s_w + row * kFc1Pitch + part * 16) =
+            *reinterpret_cast<const uint4*>(wsrc + static_cast<long>(row) * kFc1K + part * 8);
         *reinterpret_cast<uint4*>(s_a + row * kFc1Pitch + part * 16) =
             *reinterpret_cast<const uint4*>(asrc + static_cast<long>(row) * kFc1K + part * 8);
     }
     __syncthreads();
-    const char* a0 = s_a + n * kFc1Pitch + 16 * h;
-    const char* a1 = a0 + 32 * kFc1Pitch;
-    const char* bp = s_w + (wave * 32 + n) * kFc1Pitch + 16 * h;
-    f32x16 acc0 = {0}, acc1 = {0};
+    const char* ap = s_a + (rb * 32 + n) * kFc1Pitch + 16 * h;
+    const char* bp = s_w + (cb * 32 + n) * kFc1Pitch + 16 * h;
+    f32x16 acc = {0};
 #pragma unroll
-    for (int ks = 0; ks < kFc1KC / 16; ++ks) {
-        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
-        acc0 = mfma32(*reinterpret_cast<const bf16x8*>(a0 + ks * 32), bb, acc0);
-        acc1 = mfma32(*reinterpret_cast<const bf16x8*>(a1 + ks * 32), bb, acc1);
-    }
-    float* out = c.fc1_slabs + ((static_cast<long>(g) * c.S + kc) * c.B) * 128 + wave * 32 + n;
+    for (int ks = 0; ks < kFc1KC / 16; ++ks)
+        acc = mfma32(*reinterpret_cast<const bf16x8*>(ap + ks * 32),
+                     *reinterpret_cast<const bf16x8*>(bp + ks * 32), acc);
+    float* out = c.fc1_slabs + ((static_cast<long>(g) * c.S + kc) * c.B) * 128 + nh * 64 + cb * 32 + n;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        out[row * 128] = acc0[r];
-        out[(row + 32) * 128] = acc1[r];
-    }
+    for (int r = 0; r < 16; ++r) out[(rb * 32 + acc_row(r, lane)) * 128] = acc[r];
 }
 
 // ---------------------------------------------------------------------------
@@ -1791,7 +1787,7 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
             reinterpret_cast<const void*>(fc1_fwd_kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, kFc1FwdLds);
         if (lds_ok != hipSuccess) return -20;
-        hipLaunchKernelGGL(fc1_fwd_kernel, dim3(c->S, c->G), dim3(256), kFc1FwdLds, s, *c);
+        hipLaunchKernelGGL(fc1_fwd_kernel, dim3(2 * c->S, c->G), dim3(256), kFc1FwdLds, s, *c);
         break;
     }
     case 3: hipLaunchKernelGGL(head_kernel, dim3(c->B / kHeadRows, c->G), dim3(256), 0, s, *c, idx_off, step); break;
