@@ -186,112 +186,109 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16* x_in, const bf1
     }
 }
 
-// d(x) of one row per wave (the row stays in registers), plus the incoming
-// residual gradient.
-template <bool kHasRes, int NCH>
-__global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const bf16* dy, const bf16* x,
-                                                        const bf16* gamma, const float* mean,
-                                                        const float* rstd, const bf16* dres,
-                                                        bf16* dx, int R, int C, int Rg, long ps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= R) return;
-    if (ps != 0) gamma += (row / Rg) * ps;
-    const long base = static_cast<long>(row) * C;
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NCH][4], dyw[NCH][4];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c0 = ch * 256 + lane * 4;
-        if (c0 < C) {
-            float xv[4], dv[4], g[4];
-            load4(x + base + c0, xv);
-            load4(dy + base + c0, dv);
-            load4(gamma + c0, g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xh[ch][i] = (xv[i] - mu) * rs;
-                dyw[ch][i] = dv[i] * g[i];
-                s1 += dyw[ch][i];
-                s2 += dyw[ch][i] * xh[ch][i];
-            }
-        }
-    }
-    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c0 = ch * 256 + lane * 4;
-        if (c0 < C) {
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (dyw[ch][i] - m1 - xh[ch][i] * m2) * rs;
-            if (kHasRes) {
-                float r[4];
-                load4(dres + base + c0, r);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] += r[i];
-            }
-            store4(dx + base + c0, o);
-        }
-    }
-}
-
-// Column sums for d(gamma) = sum dy*xhat, d(beta) = sum dy and, of the finished
-// d(x), its column sums (the bias gradient of the projection in front of the
-// residual).  Workgroup (cx, chunk): 512 columns (8 per lane), the rows of the
-// chunk, wave w every 4th row.  partial[chunk][0..2][c].
-__global__ void __launch_bounds__(256) ln_bwd_cols_kernel(const bf16* dy, const bf16* x,
-                                                          const bf16* dx, const float* mean,
-                                                          const float* rstd, float* partial,
-                                                          int R, int C, int rows_per_chunk) {
-    __shared__ float red[4][3][512];
-    {   // blockIdx.z: group of R rows
-        const long rofs = static_cast<long>(blockIdx.z) * R;
+// d(x) and the three column sums in one pass: workgroup (chunk, group) takes the rows of its
+// chunk, wave w every NW-th row (one row at a time in registers, the next row's dy, x and
+// residual gradient already requested), and keeps per lane the running sums of its columns:
+// d(gamma) = sum dy*xhat, d(beta) = sum dy and the column sums of the finished d(x) as
+// stored (the bias gradient of the projection in front of the residual) ->
+// partial[chunk][0..2][c].  dy, x and d(x) are not read a second time by a column-sum pass.
+// dx may alias dres: a row is read and written by one wave only, and read first.
+template <bool kHasRes, int NCH, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) ln_bwd_fused_kernel(
+    const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const bf16* dres, bf16* dx,
+    float* __restrict__ partial, int R, int C, int rows_per_chunk, long ps) {
+    __shared__ float red[NW][NCH * 256];
+    {   // blockIdx.y: group of R rows
+        const long rofs = static_cast<long>(blockIdx.y) * R;
         dy += rofs * C;
         x += rofs * C;
         dx += rofs * C;
+        if (kHasRes) dres += rofs * C;
         mean += rofs;
         rstd += rofs;
-        partial += static_cast<long>(blockIdx.z) * gridDim.y * 3 * C;
+        gamma += blockIdx.y * ps;
+        partial += (static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * 3 * C;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 512 + lane * 8;
-    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r0 = blockIdx.x * rows_per_chunk;
     const int r1 = min(R, r0 + rows_per_chunk);
-    float ag[8], ab[8], as[8];
+    float ag[NCH][4], ab[NCH][4], as[NCH][4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; as[k] = 0.f; }
-    if (c < C) {
-#pragma unroll 2
-        for (int r = r0 + wave; r < r1; r += 4) {
-            const long at = static_cast<long>(r) * C + c;
-            const float mu = mean[r], rs = rstd[r];
-            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + at);
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + at);
-            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(dx + at);
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float d = bf2f(dv[k]);
-                ag[k] = fmaf(d, (bf2f(xv[k]) - mu) * rs, ag[k]);
-                ab[k] += d;
-                as[k] += bf2f(ov[k]);
+        for (int i = 0; i < 4; ++i) { ag[ch][i] = 0.f; ab[ch][i] = 0.f; as[ch][i] = 0.f; }
+    bf16x4 nx[NCH], nd[NCH], nr[NCH];
+    auto request = [&](int r) {
+        const long base = static_cast<long>(r) * C;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c0 = ch * 256 + lane * 4;
+            if (c0 < C) {
+                nx[ch] = *reinterpret_cast<const bf16x4*>(x + base + c0);
+                nd[ch] = *reinterpret_cast<const bf16x4*>(dy + base + c0);
+                if (kHasRes) nr[ch] = *reinterpret_cast<const bf16x4*>(dres + base + c0);
+            }
+        }
+    };
+    if (r0 + wave < r1) request(r0 + wave);
+    for (int r = r0 + wave; r < r1; r += NW) {
+        const long base = static_cast<long>(r) * C;
+        const float mu = mean[r], rs = rstd[r];
+        float xh[NCH][4], dyw[NCH][4];
+        bf16x4 rv[NCH];  // (kept packed: the kernel has to fit 128 registers for 16 waves per CU)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c0 = ch * 256 + lane * 4;
+            if (c0 < C) {
+                float gm[4];
+                load4(gamma + c0, gm);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = bf2f(nd[ch][i]);
+                    xh[ch][i] = (bf2f(nx[ch][i]) - mu) * rs;
+                    dyw[ch][i] = d * gm[i];
+                    s1 += dyw[ch][i];
+                    s2 += dyw[ch][i] * xh[ch][i];
+                    ag[ch][i] = fmaf(d, xh[ch][i], ag[ch][i]);
+                    ab[ch][i] += d;
+                }
+                if (kHasRes) rv[ch] = nr[ch];
+            }
+        }
+        if (r + NW < r1) request(r + NW);
+        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c0 = ch * 256 + lane * 4;
+            if (c0 < C) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = (dyw[ch][i] - m1 - xh[ch][i] * m2) * rs;
+                    if (kHasRes) o[i] += bf2f(rv[ch][i]);
+                    as[ch][i] += bf2f(f2bf(o[i]));  // the sum of what is stored
+                }
+                store4(dx + base + c0, o);
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        red[wave][0][lane * 8 + k] = ag[k];
-        red[wave][1][lane * 8 + k] = ab[k];
-        red[wave][2][lane * 8 + k] = as[k];
-    }
-    __syncthreads();
-    float* out = partial + static_cast<long>(blockIdx.y) * 3 * C;
-    for (int i = threadIdx.x; i < 3 * 512; i += 256) {
-        const int which = i / 512, col = blockIdx.x * 512 + (i % 512);
-        if (col < C)
-            out[which * C + col] = (red[0][which][i % 512] + red[1][which][i % 512]) +
-                                   (red[2][which][i % 512] + red[3][which][i % 512]);
+    for (int which = 0; which < 3; ++which) {
+        if (which > 0) __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                red[wave][ch * 256 + lane * 4 + i] =
+                    which == 0 ? ag[ch][i] : (which == 1 ? ab[ch][i] : as[ch][i]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 64 * NW) {
+            float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (NW == 8) t += (red[4][c] + red[5][c]) + (red[6][c] + red[7][c]);
+            partial[which * C + c] = t;
+        }
     }
 }
 
@@ -670,26 +667,27 @@ int nf_ln_bwd_g(const void* dy, const void* x, const void* gamma, const float* m
     bf16* dxp = static_cast<bf16*>(dx);
     const int RT = G * R;
     const long pstride = G > 1 ? ps : 0;
-    const dim3 grid((RT + 3) / 4), block(256);
-#define NF_LN_BWD(N)                                                                          \
+    const int nb = nf_ln_bwd_blocks(R);
+    const int rows = (R + nb - 1) / nb;
+    const dim3 grid(nb, G);
+    (void)RT;
+    // eight waves per workgroup, two workgroups per CU (twice the rows in flight) while the
+    // row and its sums fit 128 registers
+#define NF_LN_BWD(N, W)                                                                       \
     case N:                                                                                   \
         if (dres != nullptr)                                                                  \
-            hipLaunchKernelGGL((ln_bwd_dx_kernel<true, N>), grid, block, 0, s, dyp, xp, ga, mean, \
-                               rstd, dr, dxp, RT, C, R, pstride);                             \
+            hipLaunchKernelGGL((ln_bwd_fused_kernel<true, N, W>), grid, dim3(64 * W), 0, s, dyp, \
+                               xp, ga, mean, rstd, dr, dxp, partial, R, C, rows, pstride);    \
         else                                                                                  \
-            hipLaunchKernelGGL((ln_bwd_dx_kernel<false, N>), grid, block, 0, s, dyp, xp, ga, mean, \
-                               rstd, nullptr, dxp, RT, C, R, pstride);                        \
+            hipLaunchKernelGGL((ln_bwd_fused_kernel<false, N, W>), grid, dim3(64 * W), 0, s, dyp, \
+                               xp, ga, mean, rstd, nullptr, dxp, partial, R, C, rows, pstride); \
         break;
     switch ((C + 255) / 256) {
-        NF_LN_BWD(1) NF_LN_BWD(2) NF_LN_BWD(3) NF_LN_BWD(4)
-        NF_LN_BWD(5) NF_LN_BWD(6) NF_LN_BWD(7) NF_LN_BWD(8)
+        NF_LN_BWD(1, 8) NF_LN_BWD(2, 8) NF_LN_BWD(3, 8) NF_LN_BWD(4, 4)
+        NF_LN_BWD(5, 4) NF_LN_BWD(6, 4) NF_LN_BWD(7, 4) NF_LN_BWD(8, 4)
     default: return -1;
     }
 #undef NF_LN_BWD
-    const int nb = nf_ln_bwd_blocks(R);
-    const int rows = (R + nb - 1) / nb;
-    hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3((C + 511) / 512, nb, G), dim3(256), 0, s, dyp, xp,
-                       static_cast<const bf16*>(dx), mean, rstd, partial, R, C, rows);
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * C + 63) / 64, G), dim3(256), 0, s, partial,
                        static_cast<bf16*>(dgamma), static_cast<bf16*>(dbeta),
                        static_cast<bf16*>(dxsum), nb, C, G > 1 ? gs : 0);

@@ -236,11 +236,26 @@ def choose_splits(M: int, N: int, K: int, geo: int = GEO_128, batch: int = 1) ->
     range keeps at least 8 K steps of 64.  Outputs of a few tiles only (weight gradients
     of small layers: K is the number of pixels or tokens) have almost no slab traffic:
     they are cut into ranges as short as 4 steps, up to 64."""
+    forced = os.environ.get("NANOFED_GEMM_SPLITS")
+    if forced is not None:
+        return int(forced)
     bm, bn = _GEO_TILE[geo]
     tiles = (-(-M // bm)) * (-(-N // bn)) * batch
-    if tiles >= 200:
-        return 1
     ksteps = (K + 63) // 64
+    if tiles >= 200:
+        if geo == GEO_256 and tiles < 1024 and ksteps >= 512:
+            # one 256 x 256 workgroup per CU: a launch of a round and a half takes two rounds.
+            # With a very long reduction the slabs cost little next to the empty half round
+            # (the LM head's input gradient for 8 clients, 384 tiles, K = 50257: 2987 us
+            # unsplit, 2408 us cut in two, 2476 in four; at K = 3072 the slabs cost more than
+            # the half round: 182 against 228 us)
+            def fill(t: int) -> float:
+                return (t / 256.0) / -(-t // 256)
+            if fill(tiles) < 0.8:
+                for s in (2, 3, 4):
+                    if fill(tiles * s) >= 0.95:
+                        return s
+        return 1
     if tiles <= 16:
         return max(1, min(-(-256 // tiles), 64, ksteps // 4))
     want = max(1, (432 + tiles // 2) // tiles)
