@@ -77,6 +77,7 @@ def run_engine(name: str, args) -> dict:
         "ms_per_round": 1000 * dt / args.rounds,
         "arena_mb": engine.layout.numel * 4 / 1e6,
         "trainer": type(engine.trainer).__name__,
+        "trainer_info": dict(getattr(engine.trainer, "stream_report", None) or {}),
         "train_loss": reports[-1].agg_metrics["loss"],
         "train_accuracy": reports[-1].agg_metrics["accuracy"],
         "phases_ms": {k: round(sum(r.phases_ms.get(k, 0.0) for r in reports) / len(reports), 3)
