@@ -356,8 +356,9 @@ class GPT2NativeTrainer(GroupTrainer):
                    x.stride(0), K, Gn, R * dy.stride(0), R * x.stride(0), dw.stride, side=side)
 
     def _glin_bwd(self, dy: torch.Tensor, x: torch.Tensor, wname: str, dx: torch.Tensor, g0: int,
-                  Gn: int, R: int, n: int | None = None) -> None:
-        """Both gradients of a linear layer.  They read the same d(y) and write different
+                  Gn: int, R: int, n: int | None = None, also=None) -> None:
+        """Both gradients of a linear layer (``also``: more work that only reads d(y), e.g.
+        the bias gradient; it goes where the weight gradient goes).  They read the same d(y) and write different
         buffers, and neither fills the chip to the last round of workgroups (36-288 tiles of
         256 x 256 per launch on 256 CUs): the weight gradient goes to a second stream of the
         same priority and the main stream joins it behind the data gradient, so that nothing
@@ -367,6 +368,8 @@ class GPT2NativeTrainer(GroupTrainer):
         spread over +-3 %.)"""
         side = self._side
         if side is None:
+            if also is not None:
+                also()
             self._glin_wgrad(dy, x, wname, Gn, R, n_out=n)
             self._glin_dgrad(dy, wname, dx, g0, Gn, R, n_in=n)
             return
@@ -375,6 +378,8 @@ class GPT2NativeTrainer(GroupTrainer):
         ready.record(main)
         side.wait_event(ready)
         with torch.cuda.stream(side):
+            if also is not None:
+                also()
             self._glin_wgrad(dy, x, wname, Gn, R, n_out=n, side=True)
             done = torch.cuda.Event()
             done.record(side)
@@ -453,8 +458,8 @@ class GPT2NativeTrainer(GroupTrainer):
             self._glin_bwd(b.dres, b.att[l], p + "attn.c_proj.weight", b.datt, g0, Gn, R)
             attn_ops.causal_attention_bwd(b.qkv[l], b.att[l], b.lse[l], b.datt, b.dqkv,
                                           b.attn_scratch, b.batch, b.seq, m.n_head)
-            nn_ops.colsum_g(b.dqkv, gref(p + "attn.c_attn.bias"), Gn)
-            self._glin_bwd(b.dqkv, b.ln1[l], p + "attn.c_attn.weight", b.dln, g0, Gn, R)
+            self._glin_bwd(b.dqkv, b.ln1[l], p + "attn.c_attn.weight", b.dln, g0, Gn, R,
+                           also=lambda p=p: nn_ops.colsum_g(b.dqkv, gref(p + "attn.c_attn.bias"), Gn))
             ln_b(b.dln, b.x[l], p + "ln_1", st1, dres=b.dres,
                  dxsum=f"h.{l - 1}.c_proj.bias" if l > 0 else None)
         for j in range(Gn):
