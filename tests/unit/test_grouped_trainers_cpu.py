@@ -57,6 +57,11 @@ def test_batched_gemm_heuristics_count_the_tiles_of_all_problems():
     assert gemm_ops.choose_splits(768, 768, 4096, gemm_ops.GEO_128_2, batch=8) == 1
     # a tiny output stays split even in a batch
     assert gemm_ops.choose_splits(64, 32, 65536, gemm_ops.GEO_128_2, batch=8) > 1
+    # a round and a half of 256 x 256 workgroups with a very long reduction is cut in two
+    # (three full rounds); with a short reduction the slabs would cost more than the tail
+    assert gemm_ops.choose_splits(4096, 768, 50257, gemm_ops.GEO_256, batch=8) == 2
+    assert gemm_ops.choose_splits(4096, 768, 3072, gemm_ops.GEO_256, batch=8) == 1
+    assert gemm_ops.choose_splits(4096, 3072, 50257, gemm_ops.GEO_256, batch=8) == 1  # six full rounds
     # geometry: the tile count that selects the wide tiles is the batch's
     one = gemm_ops.choose_geometry(4096, 2304, 768, gemm_ops.NT)
     many = gemm_ops.choose_geometry(4096, 2304, 768, gemm_ops.NT, batch=8)
