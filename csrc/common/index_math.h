@@ -36,6 +36,23 @@ NF_IX int gemm_tile_index(int id, int total_tiles) {
     return start + slot;
 }
 
+// linear tile index -> tile row * 65536 + tile column.  group_m <= 1: row after row.  Else
+// bands of group_m tile rows, each walked column after column, so that consecutive tiles (the
+// ones in flight on an XCD) share group_m row panels and in_flight / group_m column panels;
+// the last band may have fewer rows.
+NF_IX int gemm_tile_rc(int t, int tiles_m, int tiles_n, int group_m) {
+    if (group_m <= 1) {
+        const int tm = t / tiles_n;
+        return tm * 65536 + (t - tm * tiles_n);
+    }
+    const int band_sz = group_m * tiles_n;
+    const int band = t / band_sz, r = t - band * band_sz;
+    const int left = tiles_m - band * group_m;
+    const int rows = left < group_m ? left : group_m;
+    const int tn = r / rows;
+    return (band * group_m + (r - tn * rows)) * 65536 + tn;
+}
+
 // ---- MNIST CNN (mnist_cnn.hip) -----------------------------------------------------
 // Both convolution images are padded, not swizzled: a fragment address is then one
 // per-lane base plus a compile-time offset (tap row, tap column, k step), so the inner

@@ -57,6 +57,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "nf_device.h"
 
@@ -81,6 +82,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     long sA, sB, sC;  // batched launches: elements between consecutive problems (blockIdx.z)
     long sBias;       // ... between their bias vectors (C2 moves with C)
+    int group_m;      // tile rows that are walked together (column after column)
 };
 
 // tanh-GELU, the arithmetic of gelu_fwd_kernel in nn_ops.hip (same bits)
@@ -143,10 +145,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Workgroup id -> (tile row, tile column): the id space is cut into 8 contiguous
 // ranges of tile indices, one per XCD (ids congruent mod 8), tiles numbered
 // column-fastest.
-__device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int t = nfix::gemm_tile_index(id, tiles_m * tiles_n);
-    tm = t / tiles_n;
-    tn = t - tm * tiles_n;
+__device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    const int rc = nfix::gemm_tile_rc(nfix::gemm_tile_index(id, tiles_m * tiles_n), tiles_m, tiles_n,
+                                      group_m);
+    tm = rc >> 16;
+    tn = rc & 65535;
 }
 
 // Tile geometry.  BM x BN outputs per workgroup; the 8 waves form WM x (8 / WM)
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     const int wm = wave / G::WN, wn = wave % G::WN;
     const int n = lane & 31, h = lane >> 5;
     int tm, tn;
-    tile_of(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+    tile_of(blockIdx.x, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     // batched launch: problem blockIdx.z of gridDim.z equally shaped ones
     g.A += blockIdx.z * g.sA;
@@ -641,6 +644,7 @@ int launch(GemmArgs g, int batch, hipStream_t stream) {
     if (lds_ok != hipSuccess) return -20;
     g.tiles_m = (g.M + G::BM - 1) / G::BM;
     g.tiles_n = (g.N + G::BN - 1) / G::BN;
+    if (g.tiles_m >= 32768 || g.tiles_n >= 65536) return -8;  // (row, column) packed in one int
     hipLaunchKernelGGL((gemm_kernel<G, A_KM, B_KM>), dim3(g.tiles_m * g.tiles_n, g.splits, batch),
                        dim3(kThreads), G::LDS, stream, g);
     return static_cast<int>(hipGetLastError());
@@ -703,6 +707,19 @@ int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void
     g.tiles_m = g.tiles_n = 0;
     g.sA = batch > 1 ? sA : 0; g.sB = batch > 1 ? sB : 0; g.sC = batch > 1 ? sC : 0;
     g.sBias = batch > 1 ? sBias : 0;
+    // Tile rows walked together: with a short reduction a 256 x 256 tile lives a few
+    // microseconds and an XCD's 32 tiles in flight fetch their operand panels at about the same
+    // time - four rows x eight columns share 12 panels where one row x 32 columns needs 33
+    // (8 clients x 4096 x 3072 x 768: data gradient 182 -> 167 us, forward 184 -> 172 us; the
+    // LM head's forward, 197 tile columns, 3100 -> 3050 us with eight rows).  Long reductions
+    // and the k-major weight gradients measured no gain or a loss.
+    const char* gm = getenv("NANOFED_GEMM_GROUPM");
+    if (gm != nullptr)
+        g.group_m = atoi(gm);
+    else if (geo == 2 && layout != 2 && K <= 1024 && M >= 2048)
+        g.group_m = N >= 16384 ? 8 : 4;
+    else
+        g.group_m = 1;
     int rc;
     switch (layout) {
     case 0: rc = launch_geo<false, false>(geo, g, batch, stream); break;

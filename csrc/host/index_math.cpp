@@ -7,6 +7,9 @@ extern "C" {
 int nf_ix_gemm_kc_off(int row, int chunk) { return nfix::gemm_kc_off(row, chunk); }
 int nf_ix_gemm_km_off(int rowb, int k, int xb) { return nfix::gemm_km_off(rowb, k, xb); }
 int nf_ix_gemm_tile_index(int id, int total) { return nfix::gemm_tile_index(id, total); }
+int nf_ix_gemm_tile_rc(int t, int tiles_m, int tiles_n, int group_m) {
+    return nfix::gemm_tile_rc(t, tiles_m, tiles_n, group_m);
+}
 int nf_ix_mnist_fwd_off(int row, int col, int chunk) { return nfix::mnist_fwd_off(row, col, chunk); }
 int nf_ix_mnist_fwd_block_dy(int m) { return nfix::mnist_fwd_block_dy(m); }
 int nf_ix_mnist_fwd_block_dx(int m) { return nfix::mnist_fwd_block_dx(m); }

@@ -15,7 +15,7 @@ from nanofed_amd import native_build
 def ix():
     native_build.build_host()
     lib = ctypes.CDLL(str(native_build.HOST_LIB))
-    for name in ("gemm_kc_off", "gemm_km_off", "gemm_tile_index", "mnist_fwd_off", "mnist_fwd_block_dy", "mnist_fwd_block_dx",
+    for name in ("gemm_kc_off", "gemm_km_off", "gemm_tile_index", "gemm_tile_rc", "mnist_fwd_off", "mnist_fwd_block_dy", "mnist_fwd_block_dx",
                  "mnist_dg_off", "lds_b128_group",
                  "mfma32_acc_row", "conv_patch_source", "conv_patch_index", "conv_patch_byte",
                  "conv_patch_frag_byte", "conv_patch_read_cycles", "conv_patch_row_pitch",
@@ -59,6 +59,17 @@ def test_every_tile_is_owned_by_exactly_one_workgroup(ix, total):
     for xcd in range(min(8, total)):
         mine = [tiles[i] for i in range(xcd, total, 8)]
         assert mine == list(range(mine[0], mine[0] + len(mine)))
+
+
+@pytest.mark.parametrize("tiles_m,tiles_n", [(16, 12), (16, 197), (3, 5), (1, 9), (7, 1), (10, 3)])
+@pytest.mark.parametrize("group_m", [1, 2, 4, 8, 16])
+def test_grouped_tile_order_visits_every_tile_once(ix, tiles_m, tiles_n, group_m):
+    seen = [ix.nf_ix_gemm_tile_rc(t, tiles_m, tiles_n, group_m) for t in range(tiles_m * tiles_n)]
+    cells = [(rc >> 16, rc & 65535) for rc in seen]
+    assert sorted(cells) == [(i, j) for i in range(tiles_m) for j in range(tiles_n)]
+    if group_m > 1 and tiles_m >= group_m:
+        # the first group_m tiles are one column of the first band
+        assert cells[:group_m] == [(i, 0) for i in range(group_m)]
 
 
 def _slots_distinct(addresses_by_lane, group_of):
