@@ -710,14 +710,15 @@ int nf_gemm_bf16_batched(int layout, int geo, const void* A, const void* B, void
     // Tile rows walked together: with a short reduction a 256 x 256 tile lives a few
     // microseconds and an XCD's 32 tiles in flight fetch their operand panels at about the same
     // time - four rows x eight columns share 12 panels where one row x 32 columns needs 33
-    // (8 clients x 4096 x 3072 x 768: data gradient 182 -> 167 us, forward 184 -> 172 us; the
-    // LM head's forward, 197 tile columns, 3100 -> 3050 us with eight rows).  Long reductions
-    // and the k-major weight gradients measured no gain or a loss.
+    // (8 clients x 4096 x 3072 x 768: data gradient 182 -> 167 us, forward 184 -> 172 us).  Long
+    // reductions and the k-major weight gradients measured no gain or a loss; the LM head's
+    // forward (197 tile columns) gained 2 % with eight rows for 8 clients and lost 11 % for one.
     const char* gm = getenv("NANOFED_GEMM_GROUPM");
     if (gm != nullptr)
         g.group_m = atoi(gm);
-    else if (geo == 2 && layout != 2 && K <= 1024 && M >= 2048)
-        g.group_m = N >= 16384 ? 8 : 4;
+    else if (geo == 2 && layout != 2 && K <= 1024 && M >= 2048 && N < 16384 &&
+             static_cast<long>((M + 255) / 256) * ((N + 255) / 256) * batch >= 1024)
+        g.group_m = 4;  // (several rounds of workgroups: with one round the order changes nothing)
     else
         g.group_m = 1;
     int rc;
