@@ -188,6 +188,28 @@ def test_captured_grouped_steps_equal_the_eager_ones_bit_for_bit(monkeypatch):
         assert torch.equal(outs[0][0], outs[1][0])
 
 
+def test_weight_gradients_on_a_second_stream_change_no_bit(monkeypatch):
+    """The grouped step with every weight-gradient GEMM (and the c_attn bias sums) on a second
+    stream beside the data-gradient GEMM of the same d(y), against the same step on one
+    stream: three rounds, captured into a graph and replayed (the graph then has two
+    branches per linear layer) and eager; losses and final model bit for bit."""
+    from nanofed_amd.engine import gpt2_native
+
+    for capture in (True, False):
+        outs = []
+        for side in (False, True):
+            monkeypatch.setattr(gpt2_native, "WGRAD_STREAM", side)
+            eng = _engine(num_clients=3, samples_per_client=16, learning_rate=0.1,
+                          graph_capture=capture)
+            assert (eng.trainer._side is not None) == side
+            assert eng.trainer.stream_report == {"wgrad_stream": int(side)}
+            reps = [eng.run_round() for _ in range(3)]
+            torch.cuda.synchronize()
+            outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reps]))
+        assert outs[0][1] == outs[1][1]
+        assert torch.equal(outs[0][0], outs[1][0])
+
+
 def test_host_token_order_is_the_stable_device_sort():
     from nanofed_amd.ops import nn_ops
 
