@@ -12,6 +12,13 @@ from .partition import (
     label_histogram,
     sized_partition,
 )
+from .tokens import (
+    find_token_file,
+    load_token_sequences,
+    open_token_stream,
+    token_windows,
+    write_token_file,
+)
 from .synthetic import (
     synthetic_cifar10,
     synthetic_cifar10_hard,
@@ -41,4 +48,9 @@ __all__ = [
     "CIFAR10_MEAN",
     "CIFAR10_STD",
     "synthetic_tokens",
+    "find_token_file",
+    "load_token_sequences",
+    "open_token_stream",
+    "token_windows",
+    "write_token_file",
 ]

@@ -40,7 +40,7 @@ class EngineConfig:
     learning_rate: float = 0.1
     weight_decay: float = 0.0
     # data
-    dataset: str = "synthetic_mnist"  # synthetic_mnist[_hard] | mnist | synthetic_cifar10[_hard] | cifar10 | synthetic_tokens
+    dataset: str = "synthetic_mnist"  # synthetic_mnist[_hard] | mnist | synthetic_cifar10[_hard] | cifar10 | synthetic_tokens | tokens
     samples_per_client: int | Sequence[int] = 7500
     partition: str = "iid"  # iid | dirichlet
     dirichlet_alpha: float = 0.1
@@ -50,6 +50,8 @@ class EngineConfig:
     # synthetic token streams: confine the Markov chain to the first ids of the
     # vocabulary (0 = all of it); the model keeps its full width
     token_active_vocab: int = 0
+    # dataset "tokens": element type of <data_dir>/train.bin and val.bin (uint16 | uint32 | ...)
+    token_dtype: str = "uint16"
     # execution
     backend: str = "auto"  # auto | native | torch
     dtype: str = "bf16"  # compute dtype of the local trainers: bf16 | fp32

@@ -30,6 +30,7 @@ from nanofed_amd.data import (
     synthetic_tokens,
 )
 from nanofed_amd.data.cifar import CIFAR10_MEAN, CIFAR10_STD, load_cifar10_arrays
+from nanofed_amd.data.tokens import load_token_sequences
 from nanofed_amd.data.mnist import MNIST_MEAN, MNIST_STD, load_mnist_arrays
 
 from .config import EngineConfig
@@ -107,14 +108,24 @@ def build_federated_data(cfg: EngineConfig) -> FederatedData:
         else:
             raise ValueError(f"unknown partition {cfg.partition!r}")
         return FederatedData("image", x, y, shards, ex, ey, mean, std)
-    if cfg.dataset == "synthetic_tokens":
+    if cfg.dataset in ("synthetic_tokens", "tokens"):
         vocab = int(cfg.model_kwargs.get("vocab_size", 50257))
-        toks = synthetic_tokens(total, cfg.seq_len, vocab, seed=cfg.seed,
-                                active_vocab=cfg.token_active_vocab)
-        ev = synthetic_tokens(
-            max(cfg.eval_samples, 1), cfg.seq_len, vocab, seed=cfg.seed + 1,
-            table_seed=cfg.seed, active_vocab=cfg.token_active_vocab,
-        )
+        if cfg.dataset == "tokens":
+            # <data_dir>/train.bin and val.bin (flat token ids, memory-mapped); a missing
+            # file falls back to the synthetic stream with a warning, like the image sets
+            toks = load_token_sequences(cfg.data_dir, "train", cfg.seq_len, total, vocab,
+                                        seed=cfg.seed, dtype=cfg.token_dtype,
+                                        synthetic_fallback=True)
+            ev = load_token_sequences(cfg.data_dir, "val", cfg.seq_len, max(cfg.eval_samples, 1),
+                                      vocab, seed=cfg.seed + 1, dtype=cfg.token_dtype,
+                                      synthetic_fallback=True)
+        else:
+            toks = synthetic_tokens(total, cfg.seq_len, vocab, seed=cfg.seed,
+                                    active_vocab=cfg.token_active_vocab)
+            ev = synthetic_tokens(
+                max(cfg.eval_samples, 1), cfg.seq_len, vocab, seed=cfg.seed + 1,
+                table_seed=cfg.seed, active_vocab=cfg.token_active_vocab,
+            )
         shards = (
             iid_partition(total, cfg.num_clients, seed=cfg.seed)
             if len(set(sizes)) == 1
