@@ -1668,8 +1668,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
             c.shadow[g * c.shadow_stride + dst] = h;
             if (w2t_at >= 0) c.w2t[g * c.w2t_stride + w2t_at] = h;
         }
-        // every reader of this step's counter ran in an earlier launch
-        if (e == 0) c.step_counter[g] += 1ull;
+        // every reader of this step's counter ran in an earlier launch - except with DP
+        // noise, which the other workgroups of THIS launch key by the counter: then the
+        // caller bumps it with a launch of its own (bump_step_kernel) behind this one
+        if (e == 0 && !(c.dp_pass == 2 && c.dp_noise_std > 0.f)) c.step_counter[g] += 1ull;
     }
 }
 
@@ -1890,6 +1892,10 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     p.dp_pass = 2;
     if (p.fuse_sgd) {
         for (int st : clip_fused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+        if (p.dp_noise_std > 0.f) {  // finalize left the step counter to a launch behind it
+            const int rc = nf_mnist_stage(&p, 14, idx_off, step, s);
+            if (rc) return rc;
+        }
     } else {
         for (int st : clip_unfused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     }

@@ -107,3 +107,33 @@ def test_dp_rounds_run_in_a_graph_report_epsilon_and_still_learn():
     assert eps == sorted(eps) and eps[0] > 0
     assert torch.isfinite(eng.global_arena.data).all()
     assert eng.evaluate()["accuracy"] > 0.3  # chance is 0.1; clipped, noisy, non-IID
+
+
+@pytest.mark.parametrize("capture", [True, False])
+def test_noisy_rounds_are_reproducible_bit_for_bit(capture):
+    """The noise of a step is keyed by (client seed, the client's step counter).  The fused
+    last launch of the step both draws noise by that counter in all of its workgroups and
+    used to advance the counter from one of them: workgroups that ran after it drew the next
+    step's noise - a different model from run to run, and for those elements the same noise
+    in two consecutive steps.  The counter now advances in a launch of its own behind it:
+    two engines with the same seed end with the same bits, and the counters count the steps."""
+    outs = []
+    for _ in range(2):
+        torch.cuda.set_device(0)
+        comm = Communicator(device=torch.device("cuda", 0))
+        cfg = EngineConfig(model="mnist_cnn", num_clients=4, samples_per_client=1024,
+                           batch_size=B, local_epochs=2, eval_samples=256, learning_rate=0.1,
+                           graph_capture=capture,
+                           dp=DPConfig(max_gradient_norm=1.0, noise_multiplier=1.1))
+        eng = FederatedEngine(cfg, comm=comm)
+        reports = eng.run(2)
+        torch.cuda.synchronize()
+        assert all(r.status == "COMPLETED" for r in reports)
+        steps = eng.trainer.buf.step_counter.clone() if hasattr(eng.trainer, "buf") else None
+        outs.append((eng.global_arena.data.clone(), [r.agg_metrics["loss"] for r in reports], steps))
+        eng.close()
+    assert outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][2] is not None:
+        # 2 rounds x 2 epochs x 16 steps per client
+        assert outs[0][2].tolist() == [64] * 4
