@@ -1,6 +1,8 @@
 """Waves 4-7 one MFMA segment behind waves 0-3 (NANOFED_GEMM_STAGGER=1) against the plain
 loop: microseconds for the batched GPT-2 layer GEMMs (8 clients), the LM head and two
-squares, and whether the outputs are the same bits."""
+squares, and whether the outputs are the same bits.  The staggered loop was measured with
+this probe and not kept (result in profiles/r3_gemm_stagger_ab.txt):
+the kernel in the tree ignores the variable, so both columns now time the same code."""
 import os
 import sys
 
