@@ -98,7 +98,9 @@ struct MnistCtx {
     unsigned long long seed;
     float lr, wd, mean, inv_std, p_drop1, p_drop2;
     float dp_clip, dp_noise_std;  // per-sample L2 bound C, noise std on the SUM (sigma * C)
-    float* dp_normsq;       // [G][B][4] squared per-sample gradient norms: fc2, conv1, conv2.weight, -
+    float* dp_normsq;       // [G][B][4] squared per-sample gradient norms: fc2, conv1, conv2.weight; the
+                            // fourth word of samples 0 / 1: low / high half of the step counter as
+                            // dp_scale saw it (the clipped pass keys its noise by it)
     float* dp_rowscale;     // [G][B] clip factor of every sample
     float* dp_c2b;          // [G][B][64] conv2.bias gradient of every sample (DP-SGD)
     int ragged;             // 1: some client runs out of batches before the others
@@ -1525,6 +1527,14 @@ __global__ void __launch_bounds__(256) dp_scale_kernel(MnistCtx c, int step) {
         const int nv = c.nvalid[g * c.nvalid_stride + step];
         const float norm = static_cast<float>(nv) * sqrtf(fmaxf(total, 0.f));
         c.dp_rowscale[bi] = fminf(1.f, c.dp_clip / (norm + 1e-6f));
+        // The step's last launch (finalize) draws noise by the step counter in all of its
+        // workgroups and advances it from one of them: they read this copy instead, taken
+        // while nothing writes the counter.
+        if (b < 2) {
+            const unsigned long long ctr = c.step_counter[g];
+            reinterpret_cast<unsigned*>(c.dp_normsq)[bi * 4 + 3] =
+                static_cast<unsigned>(b == 0 ? ctr : ctr >> 32);
+        }
     }
 }
 
@@ -1655,9 +1665,14 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
         if (dst >= 0) {
             if (c.dp_pass == 2 && c.dp_noise_std > 0.f) {
                 // the element's share of the noise block sgd_pack would draw for it
+                // (the counter as dp_scale copied it: another workgroup of this launch
+                // advances the counter itself)
                 float z[4];
-                const unsigned long long nctr =
-                    2ull * c.step_counter[g] + 0x8000000000000000ull;
+                const unsigned* aux =
+                    reinterpret_cast<const unsigned*>(c.dp_normsq) + static_cast<long>(g) * c.B * 4;
+                const unsigned long long ctr =
+                    aux[3] | (static_cast<unsigned long long>(aux[7]) << 32);
+                const unsigned long long nctr = 2ull * ctr + 0x8000000000000000ull;
                 nf::philox_samples(client_seed(c, g), nctr,
                                    static_cast<unsigned long long>(dst >> 2), 1, z);
                 s = fmaf(c.dp_noise_std / static_cast<float>(nv), z[dst & 3], s);
@@ -1668,10 +1683,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(MnistCtx c, int step) {
             c.shadow[g * c.shadow_stride + dst] = h;
             if (w2t_at >= 0) c.w2t[g * c.w2t_stride + w2t_at] = h;
         }
-        // every reader of this step's counter ran in an earlier launch - except with DP
-        // noise, which the other workgroups of THIS launch key by the counter: then the
-        // caller bumps it with a launch of its own (bump_step_kernel) behind this one
-        if (e == 0 && !(c.dp_pass == 2 && c.dp_noise_std > 0.f)) c.step_counter[g] += 1ull;
+        // every reader of this step's counter ran in an earlier launch (the DP noise above
+        // is keyed by the copy dp_scale took)
+        if (e == 0) c.step_counter[g] += 1ull;
     }
 }
 
@@ -1892,10 +1906,6 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     p.dp_pass = 2;
     if (p.fuse_sgd) {
         for (int st : clip_fused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
-        if (p.dp_noise_std > 0.f) {  // finalize left the step counter to a launch behind it
-            const int rc = nf_mnist_stage(&p, 14, idx_off, step, s);
-            if (rc) return rc;
-        }
     } else {
         for (int st : clip_unfused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     }
