@@ -116,8 +116,8 @@ def _invariance_check(comm, args) -> dict | None:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5, help="timed federated rounds")
-    ap.add_argument("--warmup", type=int, default=1, help="untimed rounds")
+    ap.add_argument("--steps", type=int, default=20, help="timed federated rounds")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed rounds")
     ap.add_argument("--clients", type=int, default=8)
     ap.add_argument("--local-epochs", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=64)
