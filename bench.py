@@ -18,7 +18,7 @@ random-init.
 Reference number: 53.48 s per round = 0.0187 rounds/s (3 clients, CPU, logged
 in examples/mnist/tutorial.ipynb:523 of the reference).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8
 """
