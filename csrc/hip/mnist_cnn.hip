@@ -49,6 +49,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "../common/philox.h"
 #include "nf_device.h"
@@ -1444,6 +1445,23 @@ __device__ __forceinline__ void conv2_wgrad_body4(const MnistCtx& c, int wg, int
             }
         }
     }
+    if (c.dp_pass == 1) {  // one image per workgroup: the accumulators are one sample's gradient
+        float sq = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (t < ntap) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sq = fmaf(acc[t][r], acc[t][r], sq);
+            }
+        sq = wave_sum(sq);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0)
+            c.dp_normsq[(static_cast<long>(g) * c.B + wg) * 4 + 2] = (red[0] + red[1]) + (red[2] + red[3]);
+        // (the tile itself is kept: finalize forms the clipped gradient from these tiles)
+    }
     float* part = c.conv2_part + (static_cast<long>(g) * c.WPC + wg) * kConv2Part;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -1475,6 +1493,19 @@ bwd_triple_kernel(MnistCtx c, int idx_off, int step, int n_dg, int n_fw) {
         fc1_wgrad_body(c, step, bx - n_dg, blockIdx.y);
     else
         conv2_wgrad_body4(c, bx - n_dg - n_fw, blockIdx.y);
+}
+
+// The norm pass of DP-SGD: conv2_dgrad and conv2_wgrad (a workgroup per image each) in one
+// launch of four-wave workgroups.
+constexpr int kDpPairLds = kDgLds > kWgLds ? kDgLds : kWgLds;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dp_pair_kernel(MnistCtx c, int idx_off, int n_dg) {
+    const int bx = blockIdx.x;
+    if (bx < n_dg)
+        conv2_dgrad_body(c, idx_off, bx, blockIdx.y);
+    else
+        conv2_wgrad_body4(c, bx - n_dg, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -1843,6 +1874,17 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
                            kTripleLds, s, *c, idx_off, step, n_dg, kFc1Tiles);
         break;
     }
+    case 18: {
+        if (c->dp_pass != 1) return -12;
+        static const hipError_t lds_ok = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(dp_pair_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, kDpPairLds);
+        if (lds_ok != hipSuccess) return -20;
+        const int n_dg = c->B * c->split;
+        hipLaunchKernelGGL(dp_pair_kernel, dim3(n_dg + c->WPC, c->G), dim3(256), kDpPairLds, s, *c,
+                           idx_off, n_dg);
+        break;
+    }
     case 12:
         if (!c->fuse_sgd || c->dp_pass == 1) return -12;
         hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step);
@@ -1897,12 +1939,19 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     }
     MnistCtx p = *c;
     static const int fwd[] = {17, 2};
-    static const int norm_pass[] = {3, 4, 6, 7, 11};
+    static const int norm_pass_split[] = {3, 4, 6, 7, 11};
+    static const int norm_pass_pair[] = {3, 4, 18, 11, -1};
+    static const bool split_norm = getenv("NANOFED_MNIST_DP_PAIR") != nullptr &&
+                                   getenv("NANOFED_MNIST_DP_PAIR")[0] == '0';
+    const int* norm_pass = split_norm ? norm_pass_split : norm_pass_pair;
     static const int clip_unfused[] = {3, 5, 8, 9};
     static const int clip_fused[] = {3, 5, 12};  // SGD + noise inside fc1_wgrad / finalize
     for (int st : fwd) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     p.dp_pass = 1;
-    for (int st : norm_pass) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+    for (int i = 0; i < 5 && norm_pass[i] >= 0; ++i) {
+        const int rc = nf_mnist_stage(&p, norm_pass[i], idx_off, step, s);
+        if (rc) return rc;
+    }
     p.dp_pass = 2;
     if (p.fuse_sgd) {
         for (int st : clip_fused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
