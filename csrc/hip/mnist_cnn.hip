@@ -616,9 +616,12 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // has one barrier: before the sums over the 8 rows (fc2's weight gradient, the bias
 // gradients, the loss).  The slabs, fc2's weights and the label are fetched first, all at
 // once - the kernel is a chain of latencies, not of arithmetic.
-__global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int step) {
-    if (client_idle(c, blockIdx.y)) return;
-    const int hb = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+// (write_dh1 = false: the caller's fc1_wgrad scales the rows of the norm pass's d(h1) by the
+// clip factors itself, see dp_clip_kernel)
+__device__ __forceinline__ void head_body(const MnistCtx& c, int idx_off, int step, int hb, int g,
+                                          bool write_dh1) {
+    if (client_idle(c, g)) return;
+    const int tid = threadIdx.x;
     __shared__ float h1s[kHeadRows][132];
     __shared__ float dvs[kHeadRows][132];  // d(h1 pre-activation)
     __shared__ float dl[kHeadRows][12];
@@ -743,7 +746,8 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
             v4[e] = v;
             o4[e] = f2bf(v);
         }
-        *reinterpret_cast<bf16x4*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o4;
+        if (write_dh1)
+            *reinterpret_cast<bf16x4*>(c.dh1 + (static_cast<long>(g) * c.B + b) * 128 + j0) = o4;
         *reinterpret_cast<float4*>(&dvs[r][j0]) = make_float4(v4[0], v4[1], v4[2], v4[3]);
     }
     __syncthreads();
@@ -783,6 +787,10 @@ __global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int 
         part[1296 + tid] = acc;
     }
     if (tid == 0) { part[1424] = loss_sum; part[1425] = correct; }
+}
+
+__global__ void __launch_bounds__(256) head_kernel(MnistCtx c, int idx_off, int step) {
+    head_body(c, idx_off, step, blockIdx.x, blockIdx.y, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -886,7 +894,10 @@ __global__ void __launch_bounds__(256) fc1_dgrad_kernel(MnistCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int tile, int g) {
+// scale_rows: d(h1) in memory is the norm pass's; row b is multiplied by the clip factor of
+// sample b while it is staged (DP-SGD, clipped pass in one launch with the head).
+__device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int tile, int g,
+                                               bool scale_rows = false) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_dh = smem;                    // [64 b][128 j]
     char* s_p2 = smem + 64 * kTrPitch128; // [64 b][128 k']
@@ -897,8 +908,13 @@ __device__ __forceinline__ void fc1_wgrad_body(const MnistCtx& c, int step, int 
     const bf16* p2 = c.p2 + static_cast<long>(g) * c.B * kFc1K + tile * 128;
     for (int p = tid; p < 1024; p += 256) {
         const int row = p >> 4, part = p & 15;
-        *reinterpret_cast<uint4*>(s_dh + row * kTrPitch128 + part * 16) =
-            *reinterpret_cast<const uint4*>(dh + row * 128 + part * 8);
+        bf16x8 dv = *reinterpret_cast<const bf16x8*>(dh + row * 128 + part * 8);
+        if (scale_rows) {
+            const float scl = c.dp_rowscale[static_cast<long>(g) * c.B + row];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dv[k] = f2bf(bf2f(dv[k]) * scl);
+        }
+        *reinterpret_cast<bf16x8*>(s_dh + row * kTrPitch128 + part * 16) = dv;
         *reinterpret_cast<uint4*>(s_p2 + row * kTrPitch128 + part * 16) =
             *reinterpret_cast<const uint4*>(p2 + static_cast<long>(row) * kFc1K + part * 8);
     }
@@ -1508,6 +1524,18 @@ dp_pair_kernel(MnistCtx c, int idx_off, int n_dg) {
         conv2_wgrad_body4(c, bx - n_dg, blockIdx.y);
 }
 
+// The clipped pass of DP-SGD: the head (fc2 gradients, metrics, fc1 bias gradient from the
+// clipped rows) and fc1_wgrad in one launch.  Both only need the clip factors: fc1_wgrad reads
+// the norm pass's d(h1) and scales its rows itself, so the head does not write d(h1) here.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dp_clip_kernel(MnistCtx c, int idx_off, int step, int n_head) {
+    const int bx = blockIdx.x;
+    if (bx < n_head)
+        head_body(c, idx_off, step, bx, blockIdx.y, false);
+    else
+        fc1_wgrad_body(c, step, bx - n_head, blockIdx.y, true);
+}
+
 // ---------------------------------------------------------------------------
 // DP-SGD, between the norm pass and the clipped pass: one workgroup per sample
 // adds the analytic parts (fc1: ||dh1||^2 (||p2||^2 + 1); conv2.bias: per-channel
@@ -1885,6 +1913,13 @@ int nf_mnist_stage(const MnistCtx* c, int stage, int idx_off, int step, hipStrea
                            idx_off, n_dg);
         break;
     }
+    case 19: {
+        if (c->dp_pass != 2 || !c->fuse_sgd) return -12;
+        const int n_head = c->B / kHeadRows;
+        hipLaunchKernelGGL(dp_clip_kernel, dim3(n_head + kFc1Tiles, c->G), dim3(256),
+                           2 * 64 * kTrPitch128, s, *c, idx_off, step, n_head);
+        break;
+    }
     case 12:
         if (!c->fuse_sgd || c->dp_pass == 1) return -12;
         hipLaunchKernelGGL(finalize_kernel<true>, dim3((kSmallTotal + 63) / 64, c->G), dim3(256), 0, s, *c, step);
@@ -1945,7 +1980,11 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
                                    getenv("NANOFED_MNIST_DP_PAIR")[0] == '0';
     const int* norm_pass = split_norm ? norm_pass_split : norm_pass_pair;
     static const int clip_unfused[] = {3, 5, 8, 9};
-    static const int clip_fused[] = {3, 5, 12};  // SGD + noise inside fc1_wgrad / finalize
+    static const int clip_fused_split[] = {3, 5, 12};  // SGD + noise inside fc1_wgrad / finalize
+    static const int clip_fused_pair[] = {19, 12, -1};
+    static const bool split_clip = getenv("NANOFED_MNIST_DP_CLIP_PAIR") != nullptr &&
+                                   getenv("NANOFED_MNIST_DP_CLIP_PAIR")[0] == '0';
+    const int* clip_fused = split_clip ? clip_fused_split : clip_fused_pair;
     for (int st : fwd) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     p.dp_pass = 1;
     for (int i = 0; i < 5 && norm_pass[i] >= 0; ++i) {
@@ -1954,7 +1993,10 @@ int nf_mnist_train_step(const MnistCtx* c, int idx_off, int step, hipStream_t s)
     }
     p.dp_pass = 2;
     if (p.fuse_sgd) {
-        for (int st : clip_fused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
+        for (int i = 0; i < 3 && clip_fused[i] >= 0; ++i) {
+            const int rc = nf_mnist_stage(&p, clip_fused[i], idx_off, step, s);
+            if (rc) return rc;
+        }
     } else {
         for (int st : clip_unfused) { const int rc = nf_mnist_stage(&p, st, idx_off, step, s); if (rc) return rc; }
     }

@@ -56,7 +56,7 @@ STAGES = {
     "conv1_fwd": 0, "conv2_fwd": 1, "fc1_fwd": 2, "head": 3, "fc1_dgrad": 4,
     "fc1_wgrad": 5, "conv2_dgrad": 6, "conv2_wgrad": 7, "finalize": 8,
     "sgd_pack": 9, "pack": 10, "dp_scale": 11, "finalize_sgd": 12, "bwd_pair": 13,
-    "bwd_triple": 16, "conv12_fwd": 17, "dp_pair": 18,
+    "bwd_triple": 16, "conv12_fwd": 17, "dp_pair": 18, "dp_clip": 19,
 }
 
 
