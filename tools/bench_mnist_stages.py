@@ -40,7 +40,10 @@ def main() -> None:
     buf.train_steps(0, 2)  # realistic activations / gradients in every buffer
     torch.cuda.synchronize()
     out = {}
-    skip = ("pack", "finalize_sgd", "bwd_pair") if args.dp else ("pack", "dp_scale")
+    # (stages that refuse the mode: the shared backward launches are for plain SGD, dp_pair
+    # belongs to the norm pass - the context of a DP trainer is set up for the clipped pass)
+    skip = (("pack", "finalize_sgd", "bwd_pair", "bwd_triple", "dp_pair") if args.dp
+            else ("pack", "dp_scale", "dp_pair", "dp_clip"))
     order = [n for n in STAGES if n not in skip]
     if args.only:
         order = args.only.split(",")
